@@ -1,0 +1,439 @@
+// Flash-style attention for head_dim 64 on gfx950: forward, dQ and dK/dV kernels.
+// No N x N score matrix is ever written to HBM.
+//
+// Orientation (v_mfma_f32_32x32x16_bf16, accumulator map col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)):
+//   forward / dQ kernels are QUERY-major: S^T = K.Q^T puts the query on the lane, so the softmax row
+//   statistics (running max, sum, LSE, delta) are per-lane scalars shared only with lane^32, and the
+//   P^T / dS^T accumulators are directly the B operands of the following products (O^T = V^T.P^T,
+//   dQ^T = K^T.dS^T) with no lane movement.  V^T / K^T reach the A operand through the transposed LDS
+//   read (ds_read_b64_tr_b16) of a [key][d] image whose 192-B row stride keeps the reads conflict-free.
+//   dK/dV kernel is KEY-major: S = Q.K^T and dP = dO.V^T put the key on the lane; each wave keeps
+//   dK^T, dV^T of its 32 keys in accumulators while the workgroup sweeps the queries, so dK/dV need no
+//   cross-workgroup sum; P and dS accumulators are again the B operands of dV^T += dO^T.P and
+//   dK^T += Q^T.dS.  dQ is produced by the separate query-major kernel (recomputing S and dP) instead
+//   of fp32 atomics, which keeps all three gradients bitwise reproducible.
+// Row-read operands (K, V, Q, dO by rows) use a 128-B-row image with the 16-B chunk XOR ((row>>1)&7).
+// Softmax is computed in the exp2 domain: p = exp2(s*scale*log2e - L2), L2 = m + log2(sum) saved per row.
+#include "common.hpp"
+#include "diffusion_amd.h"
+
+namespace {
+
+struct AttnParams {
+  const bf16 *Q, *K, *V, *O, *dO;
+  bf16 *Out, *dQ, *dK, *dV;
+  float *L2, *Delta;
+  long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int B, H, Nq, Nk;
+  float sc;     // softmax scale * log2(e)
+  float scale;  // softmax scale
+};
+
+constexpr int TR_LD = 192;  // bytes per row of a transposed-read image ([rows][64 bf16] + pad)
+
+DEVINL int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+DEVINL bf16x8 tr_frag(const char* img, int row0, int col0, int lane) {
+  // A operand of the 32x32x16 MFMA for (rows = columns col0..col0+31 of the image, k = 16 image rows
+  // starting at row0) in the accumulator-as-operand k order: element j <-> image row
+  // row0 + 8*(j>>2) + 4*(lane>>5) + (j&3).
+  const int gg = lane >> 4, dgrp = gg & 1, hh = gg >> 1, qq = (lane >> 2) & 3, pp = lane & 3;
+  const char* a = img + (row0 + 4 * hh + qq) * TR_LD + (col0 + 16 * dgrp + 4 * pp) * 2;
+  short4v t0 = lds_tr16_b64(a);
+  short4v t1 = lds_tr16_b64(a + 8 * TR_LD);
+  typedef __attribute__((ext_vector_type(8))) short short8v;
+  short8v v = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+DEVINL bf16x8 pack8(const f32x16& x, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = f2bf(x[8 * s + j]);
+  return r;
+}
+
+DEVINL int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[64 * 128 + 64 * TR_LD];
+  char* Ks = smem;
+  char* Vs = smem + 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q = blockIdx.x * 128 + wave * 32 + r;
+  const bool qv = q < p.Nq;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = qv ? ld8(p.Q + ((long)b * p.Nq + q) * p.ldq + hd * 64 + ks * 16 + h * 8) : zero8();
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+
+  const int nt = (p.Nk + 63) / 64;
+  const int lrow = tid >> 3, lchunk = tid & 7;
+  bf16x8 rk[2], rv[2];
+  auto load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = t * 64 + lrow + 32 * i;
+      bool ok = key < p.Nk;
+      long base = ((long)b * p.Nk + key);
+      rk[i] = ok ? ld8(p.K + base * p.ldk + hd * 64 + lchunk * 8) : zero8();
+      rv[i] = ok ? ld8(p.V + base * p.ldv + hd * 64 + lchunk * 8) : zero8();
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int row = lrow + 32 * i;
+      *reinterpret_cast<bf16x8*>(Ks + swz128(row, lchunk)) = rk[i];
+      *reinterpret_cast<bf16x8*>(Vs + row * TR_LD + lchunk * 16) = rv[i];
+    }
+  };
+
+  load(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    store();
+    __syncthreads();
+    if (t + 1 < nt) load(t + 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int kb = half * 32;
+      if (t * 64 + kb >= p.Nk) break;
+      f32x16 s;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + swz128(kb + r, 2 * ks + h));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int key = t * 64 + kb + acc_row(i, lane);
+        s[i] = key < p.Nk ? s[i] * p.sc : -INFINITY;
+        mx = fmaxf(mx, s[i]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float alpha = exp2f(m - mn);
+      float ls = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s[i] = exp2f(s[i] - mn);
+        ls += s[i];
+      }
+      l = l * alpha + ls;
+      m = mn;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+      bf16x8 pf[2] = {pack8(s, 0), pack8(s, 1)};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 v0 = tr_frag(Vs, kb + 16 * s2, 0, lane);
+        bf16x8 v1 = tr_frag(Vs, kb + 16 * s2, 32, lane);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[s2], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[s2], o1, 0, 0, 0);
+      }
+    }
+  }
+  const float lt = l + __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / lt;
+  if (qv) {
+    bf16* op = p.Out + ((long)b * p.Nq + q) * p.ldo + hd * 64;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      bf16x4 a, c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = f2bf(o0[rg * 4 + e] * inv);
+        c[e] = f2bf(o1[rg * 4 + e] * inv);
+      }
+      *reinterpret_cast<bf16x4*>(op + 8 * rg + 4 * h) = a;
+      *reinterpret_cast<bf16x4*>(op + 32 + 8 * rg + 4 * h) = c;
+    }
+    if (h == 0) p.L2[((long)b * p.H + hd) * p.Nq + q] = m + log2f(lt);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, query-major: dQ (and delta = rowsum(dO*O), stored for the dK/dV kernel)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128 + 64 * TR_LD];
+  char* Ks = smem;
+  char* Vs = smem + 64 * 128;
+  char* Kt = smem + 2 * 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q = blockIdx.x * 128 + wave * 32 + r;
+  const bool qv = q < p.Nq;
+
+  bf16x8 qf[4], dof[4];
+  float delta = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = hd * 64 + ks * 16 + h * 8;
+    qf[ks] = qv ? ld8(p.Q + ((long)b * p.Nq + q) * p.ldq + c) : zero8();
+    dof[ks] = qv ? ld8(p.dO + ((long)b * p.Nq + q) * p.lddo + c) : zero8();
+    bf16x8 of = qv ? ld8(p.O + ((long)b * p.Nq + q) * p.ldo + c) : zero8();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) delta += bf2f(dof[ks][j]) * bf2f(of[j]);
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  const long statidx = ((long)b * p.H + hd) * p.Nq + q;
+  const float L2q = qv ? p.L2[statidx] : 0.f;
+  if (qv && h == 0) p.Delta[statidx] = delta;
+
+  f32x16 d0, d1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { d0[i] = 0.f; d1[i] = 0.f; }
+
+  const int nt = (p.Nk + 63) / 64;
+  const int lrow = tid >> 3, lchunk = tid & 7;
+  bf16x8 rk[2], rv[2];
+  auto load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = t * 64 + lrow + 32 * i;
+      bool ok = key < p.Nk;
+      long base = ((long)b * p.Nk + key);
+      rk[i] = ok ? ld8(p.K + base * p.ldk + hd * 64 + lchunk * 8) : zero8();
+      rv[i] = ok ? ld8(p.V + base * p.ldv + hd * 64 + lchunk * 8) : zero8();
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int row = lrow + 32 * i;
+      *reinterpret_cast<bf16x8*>(Ks + swz128(row, lchunk)) = rk[i];
+      *reinterpret_cast<bf16x8*>(Vs + swz128(row, lchunk)) = rv[i];
+      *reinterpret_cast<bf16x8*>(Kt + row * TR_LD + lchunk * 16) = rk[i];
+    }
+  };
+
+  load(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    store();
+    __syncthreads();
+    if (t + 1 < nt) load(t + 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int kb = half * 32;
+      if (t * 64 + kb >= p.Nk) break;
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + swz128(kb + r, 2 * ks + h));
+        bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + swz128(kb + r, 2 * ks + h));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int key = t * 64 + kb + acc_row(i, lane);
+        float pv = key < p.Nk ? exp2f(s[i] * p.sc - L2q) : 0.f;
+        s[i] = pv * (dp[i] - delta);
+      }
+      bf16x8 dsf[2] = {pack8(s, 0), pack8(s, 1)};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 k0 = tr_frag(Kt, kb + 16 * s2, 0, lane);
+        bf16x8 k1 = tr_frag(Kt, kb + 16 * s2, 32, lane);
+        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, dsf[s2], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, dsf[s2], d1, 0, 0, 0);
+      }
+    }
+  }
+  if (qv) {
+    bf16* op = p.dQ + ((long)b * p.Nq + q) * p.lddq + hd * 64;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      bf16x4 a, c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = f2bf(d0[rg * 4 + e] * p.scale);
+        c[e] = f2bf(d1[rg * 4 + e] * p.scale);
+      }
+      *reinterpret_cast<bf16x4*>(op + 8 * rg + 4 * h) = a;
+      *reinterpret_cast<bf16x4*>(op + 32 + 8 * rg + 4 * h) = c;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, key-major: dK, dV.  Workgroup = 128 keys (4 waves x 32), sweeps all queries in 32-row tiles.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 32 * 128 + 2 * 32 * TR_LD + 2 * 32 * 4];
+  char* Qs = smem;                       // row-read image of the Q tile
+  char* Os = smem + 32 * 128;            // row-read image of the dO tile
+  char* Qt = smem + 2 * 32 * 128;        // transposed-read image of Q
+  char* Ot = Qt + 32 * TR_LD;            // transposed-read image of dO
+  float* Ls = reinterpret_cast<float*>(Ot + 32 * TR_LD);
+  float* Ds = Ls + 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int key = blockIdx.x * 128 + wave * 32 + r;
+  const bool kv = key < p.Nk;
+
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = hd * 64 + ks * 16 + h * 8;
+    kf[ks] = kv ? ld8(p.K + ((long)b * p.Nk + key) * p.ldk + c) : zero8();
+    vf[ks] = kv ? ld8(p.V + ((long)b * p.Nk + key) * p.ldv + c) : zero8();
+  }
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
+
+  const int nt = (p.Nq + 31) / 32;
+  const int lrow = tid >> 3, lchunk = tid & 7;  // 32 rows x 8 chunks = 256 threads
+  bf16x8 rq, rdo;
+  float rl = 0.f, rd = 0.f;
+  auto load = [&](int t) {
+    int qq = t * 32 + lrow;
+    bool ok = qq < p.Nq;
+    long base = ((long)b * p.Nq + qq);
+    rq = ok ? ld8(p.Q + base * p.ldq + hd * 64 + lchunk * 8) : zero8();
+    rdo = ok ? ld8(p.dO + base * p.lddo + hd * 64 + lchunk * 8) : zero8();
+    if (tid < 32) {
+      int q2 = t * 32 + tid;
+      bool ok2 = q2 < p.Nq;
+      long si = ((long)b * p.H + hd) * p.Nq + q2;
+      rl = ok2 ? p.L2[si] : 0.f;
+      rd = ok2 ? p.Delta[si] : 0.f;
+    }
+  };
+  auto store = [&]() {
+    *reinterpret_cast<bf16x8*>(Qs + swz128(lrow, lchunk)) = rq;
+    *reinterpret_cast<bf16x8*>(Os + swz128(lrow, lchunk)) = rdo;
+    *reinterpret_cast<bf16x8*>(Qt + lrow * TR_LD + lchunk * 16) = rq;
+    *reinterpret_cast<bf16x8*>(Ot + lrow * TR_LD + lchunk * 16) = rdo;
+    if (tid < 32) {
+      Ls[tid] = rl;
+      Ds[tid] = rd;
+    }
+  };
+
+  load(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    store();
+    __syncthreads();
+    if (t + 1 < nt) load(t + 1);
+    f32x16 s, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + swz128(r, 2 * ks + h));
+      bf16x8 of = *reinterpret_cast<const bf16x8*>(Os + swz128(r, 2 * ks + h));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);     // S[q][key]
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[ks], dp, 0, 0, 0);   // dP[q][key]
+    }
+    f32x16 pr;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + 8 * rg + 4 * h);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + 8 * rg + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = rg * 4 + e;
+        float pv = exp2f(s[i] * p.sc - l4[e]);
+        pr[i] = pv;
+        s[i] = pv * (dp[i] - d4[e]);
+      }
+    }
+    // rows beyond Nq in the last tile: Q = dO = 0, L2 = delta = 0 -> p = 1, dS = 0, and dO^T.P adds 0.
+    bf16x8 pf[2] = {pack8(pr, 0), pack8(pr, 1)};
+    bf16x8 dsf[2] = {pack8(s, 0), pack8(s, 1)};
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 ot0 = tr_frag(Ot, 16 * s2, 0, lane);
+      bf16x8 ot1 = tr_frag(Ot, 16 * s2, 32, lane);
+      bf16x8 qt0 = tr_frag(Qt, 16 * s2, 0, lane);
+      bf16x8 qt1 = tr_frag(Qt, 16 * s2, 32, lane);
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot0, pf[s2], dv0, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot1, pf[s2], dv1, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt0, dsf[s2], dk0, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt1, dsf[s2], dk1, 0, 0, 0);
+    }
+  }
+  if (kv) {
+    bf16* kp = p.dK + ((long)b * p.Nk + key) * p.lddk + hd * 64;
+    bf16* vp = p.dV + ((long)b * p.Nk + key) * p.lddv + hd * 64;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      bf16x4 a, c, e0, e1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = f2bf(dk0[rg * 4 + e] * p.scale);
+        c[e] = f2bf(dk1[rg * 4 + e] * p.scale);
+        e0[e] = f2bf(dv0[rg * 4 + e]);
+        e1[e] = f2bf(dv1[rg * 4 + e]);
+      }
+      *reinterpret_cast<bf16x4*>(kp + 8 * rg + 4 * h) = a;
+      *reinterpret_cast<bf16x4*>(kp + 32 + 8 * rg + 4 * h) = c;
+      *reinterpret_cast<bf16x4*>(vp + 8 * rg + 4 * h) = e0;
+      *reinterpret_cast<bf16x4*>(vp + 32 + 8 * rg + 4 * h) = e1;
+    }
+  }
+}
+
+int check(long ld) { return (ld & 7) ? 1 : 0; }
+
+}  // namespace
+
+extern "C" int da_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
+                           long ldo, float* L2, int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return DA_ERR_SHAPE;
+  if (check(ldq) || check(ldk) || check(ldv) || check(ldo)) return DA_ERR_SHAPE;
+  AttnParams p = {};
+  p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.Out = (bf16*)O; p.L2 = L2;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
+  p.scale = scale; p.sc = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const void* O,
+                           long ldo, const void* dO, long lddo, const float* L2, float* Delta, void* dQ, long lddq,
+                           void* dK, long lddk, void* dV, long lddv, int B, int H, int Nq, int Nk, float scale,
+                           hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return DA_ERR_SHAPE;
+  if (check(ldq) || check(ldk) || check(ldv) || check(ldo) || check(lddo) || check(lddq) || check(lddk) ||
+      check(lddv))
+    return DA_ERR_SHAPE;
+  AttnParams p = {};
+  p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.O = (const bf16*)O; p.dO = (const bf16*)dO;
+  p.dQ = (bf16*)dQ; p.dK = (bf16*)dK; p.dV = (bf16*)dV;
+  p.L2 = const_cast<float*>(L2); p.Delta = Delta;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+  p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
+  p.scale = scale; p.sc = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, p);
+  DA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Nk + 127) / 128, H, B), dim3(256), 0, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}

@@ -1,0 +1,270 @@
+// Implicit-GEMM "NT" kernel for gfx950:  C[M,N] = alpha * gather(A)[M,K] . W[N,K]^T  (+bias +rowbias +R)
+//
+// One kernel serves every K-contiguous contraction of the U-Net step:
+//   * 3x3 / 1x1 convolution forward on NHWC activations, im2col-free: the A row of output pixel m for
+//     tap (r,s) is the channel vector of input pixel (oh*stride+r-1, ow*stride+s-1); out-of-image taps
+//     read zeros.  K = taps*Cin, W is [Cout][r][s][Cin].
+//   * convolution dgrad: the same gather over dY with the flipped/transposed weight shadow
+//     Wt[Cin][2-r][2-s][Cout] (mode 2 handles the stride-2 downsampler's dgrad parity rule).
+//   * linear forward / dgrad (ksize 1, one "pixel" per row).
+// Tile: 128(M) x 128(N) x 64(K) per 256-thread workgroup; 4 waves as 2x2, each 64x64 built from
+// 4x4 v_mfma_f32_16x16x32_bf16 accumulators (fp32).  Global -> registers -> LDS staging (the gather
+// and zero padding need per-row predicates, so no LDS-DMA), two LDS buffers, one barrier per K-step.
+// LDS image per operand: [128 rows][64 k] bf16, 128-B rows, 16-B chunk index XOR ((row>>1)&7) so the
+// ds_read_b128 fragment reads of the 16x16x32 operand map are bank-conflict free.
+// Epilogue: accumulators -> per-wave fp32 LDS tile -> full 16-B row segments with fused
+// bias / per-image row bias (timestep FiLM) / residual add -> bf16 (or fp32) global stores.
+#include "common.hpp"
+#include "diffusion_amd.h"
+
+namespace {
+
+struct GemmNTParams {
+  const bf16* A;
+  const bf16* W;
+  void* C;
+  const float* bias;
+  const bf16* rowbias;
+  const bf16* R;
+  long lda, ldc, ldrb, ldr;
+  int M, N, K, Cin;
+  int Hin, Win, Hout, Wout;
+  int ksize, mode;
+  int out_fp32;
+  float alpha;
+  int tiles_m, tiles_n;
+};
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;          // 32 KiB
+constexpr int EPI_LD = 68;                               // fp32 row stride of the epilogue tile
+constexpr int EPI_BYTES = 4 * 64 * EPI_LD * 4;           // 69632
+constexpr int SMEM_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+
+DEVINL int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware remap: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles.
+  const int nblk = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int scol = tid & 7;
+  const int srow = tid >> 3;
+  const int HWo = p.Hout * p.Wout;
+  const int pad = (p.ksize == 3) ? 1 : 0;
+
+  int pixbase[4], oh[4], ow[4];
+  bool mval[4];
+  const bf16* wptr[4];
+  bool nval[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + srow + 32 * i;
+    mval[i] = m < p.M;
+    int mm = mval[i] ? m : 0;
+    int b = mm / HWo;
+    int rem = mm - b * HWo;
+    oh[i] = rem / p.Wout;
+    ow[i] = rem - oh[i] * p.Wout;
+    pixbase[i] = b * p.Hin * p.Win;
+    int n = n0 + srow + 32 * i;
+    nval[i] = n < p.N;
+    wptr[i] = p.W + (long)(nval[i] ? n : 0) * p.K;
+  }
+
+  int kk = scol * 8;
+  int tap = kk / p.Cin;
+  int cc = kk - tap * p.Cin;
+
+  bf16x8 ra[4], rb[4];
+  auto load_tile = [&]() {
+    const bool kval = kk < p.K;
+    int r = 0, s = 0;
+    if (p.ksize == 3) {
+      r = tap / 3;
+      s = tap - 3 * r;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int ih, iw;
+      bool ok = kval && mval[i];
+      if (p.mode == 0) {
+        ih = oh[i] + r - pad;
+        iw = ow[i] + s - pad;
+      } else if (p.mode == 1) {
+        ih = 2 * oh[i] + r - pad;
+        iw = 2 * ow[i] + s - pad;
+      } else if (p.mode == 2) {
+        int th = oh[i] + r - 1, tw = ow[i] + s - 1;
+        ok = ok && !((th | tw) & 1);
+        ih = th >> 1;
+        iw = tw >> 1;
+      } else {  // mode 3: conv over the nearest-2x upsampled input
+        int th = oh[i] + r - 1, tw = ow[i] + s - 1;
+        ok = ok && th >= 0 && tw >= 0 && th < p.Hout && tw < p.Wout;
+        ih = th >> 1;
+        iw = tw >> 1;
+      }
+      ok = ok && ih >= 0 && iw >= 0 && ih < p.Hin && iw < p.Win;
+      ra[i] = ok ? ld8(p.A + (long)(pixbase[i] + ih * p.Win + iw) * p.lda + cc) : zero8();
+      rb[i] = (kval && nval[i]) ? ld8(wptr[i] + kk) : zero8();
+    }
+    kk += BK;
+    cc += BK;
+    while (cc >= p.Cin) {
+      cc -= p.Cin;
+      ++tap;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* Ab = smem + buf * STAGE_BYTES;
+    char* Bb = Ab + BM * BK * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = srow + 32 * i;
+      int off = swz(row, scol);
+      *reinterpret_cast<bf16x8*>(Ab + off) = ra[i];
+      *reinterpret_cast<bf16x8*>(Bb + off) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const char* Ab = smem + buf * STAGE_BYTES;
+    const char* Bb = Ab + BM * BK * 2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[4], b[4];
+      const int chunk = s * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int row = wm * 64 + i * 16 + (lane & 15);
+        a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz(row, chunk));
+        int rowb = wn * 64 + i * 16 + (lane & 15);
+        b[i] = *reinterpret_cast<const bf16x8*>(Bb + swz(rowb, chunk));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) load_tile();
+    compute(t & 1);
+    if (t + 1 < nk) store_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc -> per-wave fp32 LDS tile -> coalesced row segments
+  float* ew = reinterpret_cast<float*>(smem) + wave * (64 * EPI_LD);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int row = i * 16 + (lane >> 4) * 4 + e;
+        int col = j * 16 + (lane & 15);
+        ew[row * EPI_LD + col] = acc[i][j][e];
+      }
+  __syncthreads();
+  const int col8 = (lane & 7) * 8;
+  const int n = n0 + wn * 64 + col8;
+  if (n < p.N) {
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n + e] : 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      int row = pass * 8 + (lane >> 3);
+      int m = m0 + wm * 64 + row;
+      if (m >= p.M) continue;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8 + 4]);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bv[e];
+      if (p.rowbias) {
+        int b = m / HWo;
+        bf16x8 rbv = ld8(p.rowbias + (long)b * p.ldrb + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f(rbv[e]);
+      }
+      if (p.R) {
+        bf16x8 rv = ld8(p.R + (long)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
+      }
+      if (p.out_fp32) {
+        float* cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+        st8(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, o);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int da_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
+                          const void* rowbias, long ldrb, const void* R, long ldr, int M, int N, int K, int Cin,
+                          int Hin, int Win, int Hout, int Wout, int ksize, int mode, int out_fp32, float alpha,
+                          hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return DA_ERR_SHAPE;
+  if ((N & 7) || (Cin & 7) || (K % Cin) || (lda & 7) || (ldc & 7)) return DA_ERR_SHAPE;
+  if (ksize != 1 && ksize != 3) return DA_ERR_SHAPE;
+  if (K != ksize * ksize * Cin) return DA_ERR_SHAPE;
+  if (mode < 0 || mode > 3) return DA_ERR_SHAPE;
+  if (Hout <= 0 || Wout <= 0 || (M % (Hout * Wout))) return DA_ERR_SHAPE;
+  if (R && (ldr & 7)) return DA_ERR_SHAPE;
+  if (rowbias && (ldrb & 7)) return DA_ERR_SHAPE;
+  GemmNTParams p;
+  p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = C; p.bias = bias;
+  p.rowbias = (const bf16*)rowbias; p.R = (const bf16*)R;
+  p.lda = lda; p.ldc = ldc; p.ldrb = ldrb; p.ldr = ldr;
+  p.M = M; p.N = N; p.K = K; p.Cin = Cin;
+  p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
+  p.ksize = ksize; p.mode = mode; p.out_fp32 = out_fp32; p.alpha = alpha;
+  p.tiles_m = (M + BM - 1) / BM;
+  p.tiles_n = (N + BN - 1) / BN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) !=
+        hipSuccess)
+      return DA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), SMEM_BYTES, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}

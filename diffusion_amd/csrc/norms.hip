@@ -1,0 +1,521 @@
+// GroupNorm / LayerNorm forward+backward and per-channel reductions on NHWC bf16 activations
+// (SURVEY.md K5, K7 and the bias-gradient column sums).  All HBM-bound: 16-B vector accesses along the
+// channel axis, fp32 statistics, wave64 shuffles / LDS for the reductions, and NO atomics - every
+// reduction is a fixed-order two-stage sum (partials per pixel chunk -> finalize), so results are
+// bitwise reproducible run to run.
+//
+// chan_reduce<MODE>: each thread owns 8 consecutive channels and walks pixels; per-(image, channel)
+//   partial sums of two quantities are written per pixel chunk:
+//     MODE 0  GroupNorm forward statistics      (x, x^2)
+//     MODE 1  GroupNorm(+SiLU) backward sums    (dz, dz*xhat),  dz = dy * silu'(z) when SiLU was fused
+//     MODE 2  column sum                         (x, -)           (bias gradients)
+#include "common.hpp"
+#include "diffusion_amd.h"
+
+namespace {
+
+struct ChanReduceParams {
+  const bf16* X;
+  const bf16* DY;
+  const float* mean_rstd;  // [B][G][2]
+  const float* gamma;
+  const float* beta;
+  float* partial;  // [B][nchunks][C][2]
+  long ldx, lddy;
+  int HW, C, G, cpg, nchunks, ppc, pxt, silu;
+};
+
+template <int MODE>
+__global__ void chan_reduce_kernel(ChanReduceParams p) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int tid = threadIdx.x;
+  const int nvec = p.C >> 3;
+  const int vec = tid % nvec, pl = tid / nvec;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * p.ppc;
+  const int p1 = min(p.HW, p0 + p.ppc);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  float mu[8], rs[8], ga[8], be[8];
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int c = 8 * vec + e;
+      int g = c / p.cpg;
+      mu[e] = p.mean_rstd[((long)b * p.G + g) * 2];
+      rs[e] = p.mean_rstd[((long)b * p.G + g) * 2 + 1];
+      ga[e] = p.gamma[c];
+      be[e] = p.beta[c];
+    }
+  }
+  for (int pix = p0 + pl; pix < p1; pix += p.pxt) {
+    const long row = (long)b * p.HW + pix;
+    bf16x8 x = ld8(p.X + row * p.ldx + 8 * vec);
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = bf2f(x[e]);
+        s1[e] += v;
+        s2[e] += v * v;
+      }
+    } else if (MODE == 1) {
+      bf16x8 dy = ld8(p.DY + row * p.lddy + 8 * vec);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float xh = (bf2f(x[e]) - mu[e]) * rs[e];
+        float dz = bf2f(dy[e]);
+        if (p.silu) dz *= dsilu_f(xh * ga[e] + be[e]);
+        s1[e] += dz;
+        s2[e] += dz * xh;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[e] += bf2f(x[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[((long)pl * p.C + 8 * vec + e) * 2] = s1[e];
+    red[((long)pl * p.C + 8 * vec + e) * 2 + 1] = s2[e];
+  }
+  __syncthreads();
+  float* out = p.partial + ((long)b * p.nchunks + chunk) * p.C * 2;
+  for (int c = tid; c < p.C; c += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < p.pxt; ++k) {
+      a += red[((long)k * p.C + c) * 2];
+      q += red[((long)k * p.C + c) * 2 + 1];
+    }
+    out[c * 2] = a;
+    out[c * 2 + 1] = q;
+  }
+}
+
+int launch_chan_reduce(int mode, ChanReduceParams& p, int B, hipStream_t stream) {
+  const int nvec = p.C >> 3;
+  if (nvec < 1 || nvec > 512) return DA_ERR_SHAPE;
+  int pxt = 512 / nvec;
+  if (pxt > p.HW) pxt = p.HW;
+  if (pxt < 1) pxt = 1;
+  p.pxt = pxt;
+  p.ppc = (p.HW + p.nchunks - 1) / p.nchunks;
+  const size_t smem = (size_t)pxt * p.C * 2 * sizeof(float);
+  dim3 grid(p.nchunks, B), block(nvec * pxt);
+  if (mode == 0) hipLaunchKernelGGL(chan_reduce_kernel<0>, grid, block, smem, stream, p);
+  else if (mode == 1) hipLaunchKernelGGL(chan_reduce_kernel<1>, grid, block, smem, stream, p);
+  else hipLaunchKernelGGL(chan_reduce_kernel<2>, grid, block, smem, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int pick_chunks(int B, int HW) {
+  int n = 2048 / (B > 0 ? B : 1);
+  if (n > 64) n = 64;
+  int maxc = HW / 16;
+  if (n > maxc) n = maxc;
+  if (n < 1) n = 1;
+  return n;
+}
+
+// ---- GroupNorm forward finalize: partial -> mean/rstd [B][G][2] and per-(b,c) scale/shift [B][C][2]
+__global__ void gn_fwd_finalize_kernel(const float* partial, const float* gamma, const float* beta, float* mean_rstd,
+                                       float* scale_shift, int C, int G, int cpg, int nchunks, int HW, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [C][2] then [G][2]
+  float* gs = sh + 2 * C;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+      const float* pp = partial + (((long)b * nchunks + k) * C + c) * 2;
+      a += pp[0];
+      q += pp[1];
+    }
+    sh[2 * c] = a;
+    sh[2 * c + 1] = q;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < cpg; ++k) {
+      a += sh[2 * (g * cpg + k)];
+      q += sh[2 * (g * cpg + k) + 1];
+    }
+    const float n = (float)cpg * (float)HW;
+    float mean = a / n;
+    float var = fmaxf(q / n - mean * mean, 0.f);
+    float rstd = rsqrtf(var + eps);
+    gs[2 * g] = mean;
+    gs[2 * g + 1] = rstd;
+    mean_rstd[((long)b * G + g) * 2] = mean;
+    mean_rstd[((long)b * G + g) * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    int g = c / cpg;
+    float sc = gs[2 * g + 1] * gamma[c];
+    scale_shift[((long)b * C + c) * 2] = sc;
+    scale_shift[((long)b * C + c) * 2 + 1] = beta[c] - gs[2 * g] * sc;
+  }
+}
+
+// y = x*scale + shift (+SiLU)
+__global__ void gn_apply_kernel(const bf16* X, long ldx, bf16* Y, long ldy, const float* scale_shift, int HW, int C,
+                                long total_vec, int silu) {
+  const int nvec = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec; i += (long)gridDim.x * blockDim.x) {
+    long row = i / nvec;
+    int vec = (int)(i - row * nvec);
+    int b = (int)(row / HW);
+    bf16x8 x = ld8(X + row * ldx + 8 * vec);
+    const float* ss = scale_shift + ((long)b * C + 8 * vec) * 2;
+    bf16x8 y;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float z = bf2f(x[e]) * ss[2 * e] + ss[2 * e + 1];
+      y[e] = f2bf(silu ? silu_f(z) : z);
+    }
+    st8(Y + row * ldy + 8 * vec, y);
+  }
+}
+
+// ---- GroupNorm backward finalize: per (b,g) coefficients (mean(dxhat), mean(dxhat*xhat))
+__global__ void gn_bwd_finalize_kernel(const float* partial, const float* gamma, float* coef, int C, int G, int cpg,
+                                       int nchunks, int HW) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+      const float* pp = partial + (((long)b * nchunks + k) * C + c) * 2;
+      a += pp[0];
+      q += pp[1];
+    }
+    sh[2 * c] = a * gamma[c];
+    sh[2 * c + 1] = q * gamma[c];
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < cpg; ++k) {
+      a += sh[2 * (g * cpg + k)];
+      q += sh[2 * (g * cpg + k) + 1];
+    }
+    const float n = (float)cpg * (float)HW;
+    coef[((long)b * G + g) * 2] = a / n;
+    coef[((long)b * G + g) * 2 + 1] = q / n;
+  }
+}
+
+// dx = rstd * (dz*gamma - c1 - xhat*c2) (+ Radd)
+__global__ void gn_bwd_apply_kernel(const bf16* X, long ldx, const bf16* DY, long lddy, const bf16* Radd, long ldr,
+                                    bf16* DX, long lddx, const float* mean_rstd, const float* coef,
+                                    const float* gamma, const float* beta, int HW, int C, int G, int cpg,
+                                    long total_vec, int silu) {
+  const int nvec = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec; i += (long)gridDim.x * blockDim.x) {
+    long row = i / nvec;
+    int vec = (int)(i - row * nvec);
+    int b = (int)(row / HW);
+    bf16x8 x = ld8(X + row * ldx + 8 * vec);
+    bf16x8 dy = ld8(DY + row * lddy + 8 * vec);
+    bf16x8 ra = Radd ? ld8(Radd + row * ldr + 8 * vec) : zero8();
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int c = 8 * vec + e;
+      int g = c / cpg;
+      const float mu = mean_rstd[((long)b * G + g) * 2], rs = mean_rstd[((long)b * G + g) * 2 + 1];
+      const float c1 = coef[((long)b * G + g) * 2], c2 = coef[((long)b * G + g) * 2 + 1];
+      float xh = (bf2f(x[e]) - mu) * rs;
+      float dz = bf2f(dy[e]);
+      if (silu) dz *= dsilu_f(xh * gamma[c] + beta[c]);
+      float dx = rs * (dz * gamma[c] - c1 - xh * c2);
+      o[e] = f2bf(dx + bf2f(ra[e]));
+    }
+    st8(DX + row * lddx + 8 * vec, o);
+  }
+}
+
+// out1[c] (+)= sum_rows partial[row][c][0] ; out2[c] (+)= sum_rows partial[row][c][1]
+__global__ void chan_sum_finalize_kernel(const float* partial, int nrows, int C, float* out1, float* out2,
+                                         int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, q = 0.f;
+  for (int k = 0; k < nrows; ++k) {
+    const float* pp = partial + ((long)k * C + c) * 2;
+    a += pp[0];
+    q += pp[1];
+  }
+  if (out1) out1[c] = accumulate ? out1[c] + a : a;
+  if (out2) out2[c] = accumulate ? out2[c] + q : q;
+}
+
+// out[b][c] = sum_chunks partial[b][chunk][c][0] (bf16, strided) ; db[c] += sum_b out[b][c] (fp32)
+__global__ void image_colsum_finalize_kernel(const float* partial, bf16* out, long ldo, float* db, int B, int nchunks,
+                                             int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float tot = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float a = 0.f;
+    for (int k = 0; k < nchunks; ++k) a += partial[(((long)b * nchunks + k) * C + c) * 2];
+    out[(long)b * ldo + c] = f2bf(a);
+    tot += a;
+  }
+  if (db) db[c] += tot;
+}
+
+// ---- LayerNorm: one wave per row, row kept in registers (C <= 1536)
+constexpr int LN_MAXV = 3;
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* X, long ldx, bf16* Y, long ldy, const float* gamma,
+                                                     const float* beta, float* mean_rstd, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int nvec = C >> 3;
+  const int wpb = blockDim.x >> 6;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += gridDim.x * wpb) {
+    float v[LN_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      int vec = lane + 64 * k;
+      bf16x8 x = vec < nvec ? ld8(X + (long)row * ldx + 8 * vec) : zero8();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[k][e] = bf2f(x[e]);
+        s += v[k][e];
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      int vec = lane + 64 * k;
+      if (vec < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float d = v[k][e] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) {
+      mean_rstd[2 * (long)row] = mean;
+      mean_rstd[2 * (long)row + 1] = rstd;
+    }
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      int vec = lane + 64 * k;
+      if (vec < nvec) {
+        bf16x8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = f2bf((v[k][e] - mean) * rstd * gamma[8 * vec + e] + beta[8 * vec + e]);
+        st8(Y + (long)row * ldy + 8 * vec, y);
+      }
+    }
+  }
+}
+
+// dx = rstd*(dy*gamma - mean(dy*gamma) - xhat*mean(dy*gamma*xhat)) (+Radd); per-block partial dgamma/dbeta
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* X, long ldx, const bf16* DY, long lddy,
+                                                     const bf16* Radd, long ldr, bf16* DX, long lddx,
+                                                     const float* gamma, const float* mean_rstd, float* partial,
+                                                     int M, int C) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][C][2]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = C >> 3;
+  const int wpb = blockDim.x >> 6;
+  float dg[LN_MAXV][8], db[LN_MAXV][8], ga[LN_MAXV][8];
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int vec = lane + 64 * k;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dg[k][e] = 0.f;
+      db[k][e] = 0.f;
+      ga[k][e] = vec < nvec ? gamma[8 * vec + e] : 0.f;
+    }
+  }
+  for (int row = blockIdx.x * wpb + wave; row < M; row += gridDim.x * wpb) {
+    const float mean = mean_rstd[2 * (long)row], rstd = mean_rstd[2 * (long)row + 1];
+    float xh[LN_MAXV][8], dyv[LN_MAXV][8];
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      int vec = lane + 64 * k;
+      bool ok = vec < nvec;
+      bf16x8 x = ok ? ld8(X + (long)row * ldx + 8 * vec) : zero8();
+      bf16x8 dy = ok ? ld8(DY + (long)row * lddy + 8 * vec) : zero8();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xh[k][e] = ok ? (bf2f(x[e]) - mean) * rstd : 0.f;
+        dyv[k][e] = bf2f(dy[e]);
+        float dxh = dyv[k][e] * ga[k][e];
+        a += dxh;
+        q += dxh * xh[k][e];
+        dg[k][e] += dyv[k][e] * xh[k][e];
+        db[k][e] += dyv[k][e];
+      }
+    }
+    a = wave_sum(a) / (float)C;
+    q = wave_sum(q) / (float)C;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      int vec = lane + 64 * k;
+      if (vec < nvec) {
+        bf16x8 ra = Radd ? ld8(Radd + (long)row * ldr + 8 * vec) : zero8();
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = f2bf(rstd * (dyv[k][e] * ga[k][e] - a - xh[k][e] * q) + bf2f(ra[e]));
+        st8(DX + (long)row * lddx + 8 * vec, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int vec = lane + 64 * k;
+    if (vec < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[((long)wave * C + 8 * vec + e) * 2] = dg[k][e];
+        red[((long)wave * C + 8 * vec + e) * 2 + 1] = db[k][e];
+      }
+    }
+  }
+  __syncthreads();
+  float* out = partial + (long)blockIdx.x * C * 2;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int w = 0; w < wpb; ++w) {
+      a += red[((long)w * C + c) * 2];
+      q += red[((long)w * C + c) * 2 + 1];
+    }
+    out[c * 2] = a;
+    out[c * 2 + 1] = q;
+  }
+}
+
+}  // namespace
+
+extern "C" long da_norm_scratch_floats(int B, int HW, int C) {
+  // upper bound of partial-sum floats any norm / colsum entry point below needs
+  long a = (long)B * pick_chunks(B, HW) * C * 2;
+  long b = 256L * C * 2;  // LayerNorm backward / colsum: <= 256 partial rows
+  return a > b ? a : b;
+}
+
+extern "C" int da_groupnorm_fwd(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta,
+                                float* mean_rstd, float* scale_shift, float* scratch, int B, int HW, int C, int G,
+                                float eps, int silu, hipStream_t stream) {
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 7) || (ldx & 7) || (ldy & 7)) return DA_ERR_SHAPE;
+  ChanReduceParams p = {};
+  p.X = (const bf16*)X; p.ldx = ldx; p.partial = scratch;
+  p.HW = HW; p.C = C; p.G = G; p.cpg = C / G; p.nchunks = pick_chunks(B, HW);
+  int rc = launch_chan_reduce(0, p, B, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(B), dim3(256), (size_t)(2 * C + 2 * G) * sizeof(float), stream,
+                     scratch, gamma, beta, mean_rstd, scale_shift, C, G, C / G, p.nchunks, HW, eps);
+  DA_CHECK_LAUNCH();
+  const long total_vec = (long)B * HW * (C >> 3);
+  int blocks = (int)((total_vec + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16*)X, ldx, (bf16*)Y, ldy,
+                     scale_shift, HW, C, total_vec, silu);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_groupnorm_bwd(const void* X, long ldx, const void* dY, long lddy, const void* Radd, long ldr,
+                                void* dX, long lddx, const float* gamma, const float* beta, const float* mean_rstd,
+                                float* dgamma, float* dbeta, float* coef, float* scratch, int B, int HW, int C, int G,
+                                int silu, hipStream_t stream) {
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7))
+    return DA_ERR_SHAPE;
+  if (Radd && (ldr & 7)) return DA_ERR_SHAPE;
+  ChanReduceParams p = {};
+  p.X = (const bf16*)X; p.ldx = ldx; p.DY = (const bf16*)dY; p.lddy = lddy;
+  p.mean_rstd = mean_rstd; p.gamma = gamma; p.beta = beta; p.partial = scratch;
+  p.HW = HW; p.C = C; p.G = G; p.cpg = C / G; p.nchunks = pick_chunks(B, HW); p.silu = silu;
+  int rc = launch_chan_reduce(1, p, B, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), (size_t)(2 * C) * sizeof(float), stream, scratch,
+                     gamma, coef, C, G, C / G, p.nchunks, HW);
+  DA_CHECK_LAUNCH();
+  // dgamma[c] += sum_b s2, dbeta[c] += sum_b s1
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch,
+                     B * p.nchunks, C, dbeta, dgamma, 1);
+  DA_CHECK_LAUNCH();
+  const long total_vec = (long)B * HW * (C >> 3);
+  int blocks = (int)((total_vec + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16*)X, ldx, (const bf16*)dY,
+                     lddy, (const bf16*)Radd, ldr, (bf16*)dX, lddx, mean_rstd, coef, gamma, beta, HW, C, G, C / G,
+                     total_vec, silu);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_colsum_accum(const void* X, long ldx, float* out, float* scratch, int M, int C,
+                               hipStream_t stream) {
+  if (M <= 0 || C <= 0 || (C & 7) || (ldx & 7)) return DA_ERR_SHAPE;
+  ChanReduceParams p = {};
+  p.X = (const bf16*)X; p.ldx = ldx; p.partial = scratch;
+  p.HW = M; p.C = C; p.G = 1; p.cpg = C;
+  int n = M / 64;
+  if (n > 256) n = 256;
+  if (n < 1) n = 1;
+  p.nchunks = n;
+  int rc = launch_chan_reduce(2, p, 1, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, n, C, out,
+                     (float*)nullptr, 1);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_image_colsum(const void* X, long ldx, void* out, long ldo, float* db, float* scratch, int B, int HW,
+                               int C, hipStream_t stream) {
+  if (B <= 0 || HW <= 0 || C <= 0 || (C & 7) || (ldx & 7)) return DA_ERR_SHAPE;
+  ChanReduceParams p = {};
+  p.X = (const bf16*)X; p.ldx = ldx; p.partial = scratch;
+  p.HW = HW; p.C = C; p.G = 1; p.cpg = C; p.nchunks = pick_chunks(B, HW);
+  int rc = launch_chan_reduce(2, p, B, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(image_colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, (bf16*)out,
+                     ldo, db, B, p.nchunks, C);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_layernorm_fwd(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta,
+                                float* mean_rstd, int M, int C, float eps, hipStream_t stream) {
+  if (M <= 0 || C <= 0 || (C & 7) || C > 8 * 64 * LN_MAXV || (ldx & 7) || (ldy & 7)) return DA_ERR_SHAPE;
+  int blocks = (M + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16*)X, ldx, (bf16*)Y, ldy, gamma,
+                     beta, mean_rstd, M, C, eps);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_layernorm_bwd(const void* X, long ldx, const void* dY, long lddy, const void* Radd, long ldr,
+                                void* dX, long lddx, const float* gamma, const float* mean_rstd, float* dgamma,
+                                float* dbeta, float* scratch, int M, int C, hipStream_t stream) {
+  if (M <= 0 || C <= 0 || (C & 7) || C > 8 * 64 * LN_MAXV || (ldx & 7) || (lddy & 7) || (lddx & 7))
+    return DA_ERR_SHAPE;
+  if (Radd && (ldr & 7)) return DA_ERR_SHAPE;
+  int blocks = (M + 3) / 4;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), (size_t)4 * C * 2 * sizeof(float), stream,
+                     (const bf16*)X, ldx, (const bf16*)dY, lddy, (const bf16*)Radd, ldr, (bf16*)dX, lddx, gamma,
+                     mean_rstd, scratch, M, C);
+  DA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, blocks, C,
+                     dgamma, dbeta, 1);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}

@@ -1,0 +1,318 @@
+"""Thin host wrappers over the C ABI (include/diffusion_amd.h): shape validation + pointer plumbing.
+
+Tensors are torch CUDA(HIP) tensors used as device memory only; every arithmetic op is a HIP kernel of
+libdiffusion_amd.so.  A "matrix" argument is a 2-D tensor with unit column stride; its row stride is
+passed as ld, so column slices of wider buffers (fused QKV, concat buffers) are valid arguments.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _mat(x: torch.Tensor, dtype=BF16, name='arg') -> Tuple[int, int]:
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != dtype or not x.is_cuda:
+        raise ValueError(f'{name}: need a 2-D {dtype} device matrix with unit column stride, got '
+                         f'{tuple(x.shape)} strides {x.stride()} {x.dtype} {x.device}')
+    ld = x.stride(0) if x.shape[0] > 1 else max(x.stride(0), x.shape[1])
+    if ld % 8 or x.shape[1] % 8 or (x.data_ptr() % 16):
+        raise ValueError(f'{name}: columns, row stride and base must be multiples of 8 elements / 16 bytes')
+    return x.data_ptr(), ld
+
+
+def _vec(x: Optional[torch.Tensor], n: int, name='vec') -> int:
+    if x is None:
+        return 0
+    if x.dtype != F32 or not x.is_contiguous() or x.numel() != n or not x.is_cuda:
+        raise ValueError(f'{name}: need contiguous fp32[{n}] on device, got {tuple(x.shape)} {x.dtype}')
+    return x.data_ptr()
+
+
+def _f32buf(x: torch.Tensor, min_numel: int, name='buf') -> int:
+    if x.dtype != F32 or not x.is_contiguous() or x.numel() < min_numel or not x.is_cuda:
+        raise ValueError(f'{name}: need contiguous fp32 buffer of >= {min_numel} elements')
+    return x.data_ptr()
+
+
+class Geom:
+    """Geometry of an implicit-GEMM call.  Linear layers: Geom.linear()."""
+    __slots__ = ('B', 'Hin', 'Win', 'Hout', 'Wout', 'ksize', 'mode')
+
+    def __init__(self, B, Hin, Win, Hout, Wout, ksize, mode):
+        self.B, self.Hin, self.Win, self.Hout, self.Wout, self.ksize, self.mode = B, Hin, Win, Hout, Wout, ksize, mode
+
+    @staticmethod
+    def linear(M):
+        return Geom(M, 1, 1, 1, 1, 1, 0)
+
+    @staticmethod
+    def conv(B, H, W, ksize=3):
+        return Geom(B, H, W, H, W, ksize, 0)
+
+    @staticmethod
+    def down(B, H, W):  # stride-2 conv, H x W -> H/2 x W/2
+        return Geom(B, H, W, H // 2, W // 2, 3, 1)
+
+    @staticmethod
+    def down_dgrad(B, H, W):  # dgrad of the above: "input" dY at H/2, output dX at H
+        return Geom(B, H // 2, W // 2, H, W, 3, 2)
+
+    @staticmethod
+    def up(B, H, W):  # conv over nearest-2x upsampled input
+        return Geom(B, H, W, 2 * H, 2 * W, 3, 3)
+
+
+def gemm_nt(A, W, out, g: Geom, *, bias=None, rowbias=None, residual=None, alpha=1.0):
+    """out[M,N] = alpha * gather(A) @ W^T + bias + rowbias[image] + residual.  W: bf16 [N, k*k*Cin]."""
+    a_ptr, lda = _mat(A, BF16, 'A')
+    w_ptr, ldw = _mat(W, BF16, 'W')
+    N, K = W.shape
+    Cin = A.shape[1]
+    if ldw != K or K != g.ksize * g.ksize * Cin:
+        raise ValueError(f'W must be contiguous [N, {g.ksize * g.ksize * Cin}], got {tuple(W.shape)} ld {ldw}')
+    M = g.B * g.Hout * g.Wout
+    if A.shape[0] != g.B * g.Hin * g.Win:
+        raise ValueError(f'A rows {A.shape[0]} != B*Hin*Win {g.B * g.Hin * g.Win}')
+    out_fp32 = out.dtype == F32
+    c_ptr, ldc = _mat(out, F32 if out_fp32 else BF16, 'out')
+    if tuple(out.shape) != (M, N):
+        raise ValueError(f'out shape {tuple(out.shape)} != {(M, N)}')
+    rb_ptr, ldrb = (0, 0)
+    if rowbias is not None:
+        rb_ptr, ldrb = _mat(rowbias, BF16, 'rowbias')
+        if tuple(rowbias.shape) != (g.B, N):
+            raise ValueError('rowbias must be [B, N]')
+    r_ptr, ldr = (0, 0)
+    if residual is not None:
+        r_ptr, ldr = _mat(residual, BF16, 'residual')
+        if tuple(residual.shape) != (M, N):
+            raise ValueError('residual must be [M, N]')
+    _lib.call('da_gemm_nt', a_ptr, lda, w_ptr, c_ptr, ldc, _vec(bias, N, 'bias'), rb_ptr, ldrb, r_ptr, ldr, M, N, K,
+              Cin, g.Hin, g.Win, g.Hout, g.Wout, g.ksize, g.mode, int(out_fp32), float(alpha), _stream())
+    return out
+
+
+def gemm_tn_wgrad(dY, X, dW, g: Geom):
+    """dW[N, k*k*Cin] (fp32) += dY^T @ gather(X)."""
+    dy_ptr, lddy = _mat(dY, BF16, 'dY')
+    x_ptr, ldx = _mat(X, BF16, 'X')
+    M, N = dY.shape
+    Cin = X.shape[1]
+    if M != g.B * g.Hout * g.Wout or X.shape[0] != g.B * g.Hin * g.Win:
+        raise ValueError('wgrad: row counts do not match the geometry')
+    if dW.dtype != F32 or not dW.is_contiguous() or dW.numel() != N * g.ksize * g.ksize * Cin:
+        raise ValueError(f'dW must be contiguous fp32 with {N * g.ksize * g.ksize * Cin} elements')
+    mode = g.mode
+    if mode == 2:
+        raise ValueError('wgrad has no mode 2')
+    _lib.call('da_gemm_tn_wgrad', dy_ptr, lddy, x_ptr, ldx, dW.data_ptr(), M, N, Cin, g.Hin, g.Win, g.Hout, g.Wout,
+              g.ksize, mode, _stream())
+
+
+def attn_fwd(Q, K, V, O, L2, B, H, Nq, Nk, scale):
+    q, ldq = _mat(Q, BF16, 'Q')
+    k, ldk = _mat(K, BF16, 'K')
+    v, ldv = _mat(V, BF16, 'V')
+    o, ldo = _mat(O, BF16, 'O')
+    for t, n in ((Q, Nq), (O, Nq), (K, Nk), (V, Nk)):
+        if tuple(t.shape) != (B * n, H * 64):
+            raise ValueError(f'attention operand shape {tuple(t.shape)} != {(B * n, H * 64)}')
+    _lib.call('da_attn_fwd', q, ldq, k, ldk, v, ldv, o, ldo, _f32buf(L2, B * H * Nq, 'L2'), B, H, Nq, Nk,
+              float(scale), _stream())
+
+
+def attn_bwd(Q, K, V, O, dO, L2, Delta, dQ, dK, dV, B, H, Nq, Nk, scale):
+    ptrs = []
+    for t, n, nm in ((Q, Nq, 'Q'), (K, Nk, 'K'), (V, Nk, 'V'), (O, Nq, 'O'), (dO, Nq, 'dO')):
+        if tuple(t.shape) != (B * n, H * 64):
+            raise ValueError(f'{nm} shape {tuple(t.shape)} != {(B * n, H * 64)}')
+        ptrs += list(_mat(t, BF16, nm))
+    outs = []
+    for t, n, nm in ((dQ, Nq, 'dQ'), (dK, Nk, 'dK'), (dV, Nk, 'dV')):
+        if tuple(t.shape) != (B * n, H * 64):
+            raise ValueError(f'{nm} shape {tuple(t.shape)} != {(B * n, H * 64)}')
+        outs += list(_mat(t, BF16, nm))
+    _lib.call('da_attn_bwd', *ptrs, _f32buf(L2, B * H * Nq, 'L2'), _f32buf(Delta, B * H * Nq, 'Delta'), *outs, B, H,
+              Nq, Nk, float(scale), _stream())
+
+
+def norm_scratch_floats(B, HW, C) -> int:
+    return int(_lib.load().da_norm_scratch_floats(B, HW, C))
+
+
+def groupnorm_fwd(X, Y, gamma, beta, mean_rstd, scale_shift, scratch, B, HW, C, G, eps, silu):
+    x, ldx = _mat(X, BF16, 'X')
+    y, ldy = _mat(Y, BF16, 'Y')
+    if tuple(X.shape) != (B * HW, C) or tuple(Y.shape) != (B * HW, C):
+        raise ValueError('groupnorm: bad shapes')
+    _lib.call('da_groupnorm_fwd', x, ldx, y, ldy, _vec(gamma, C), _vec(beta, C), _f32buf(mean_rstd, B * G * 2),
+              _f32buf(scale_shift, B * C * 2), _f32buf(scratch, norm_scratch_floats(B, HW, C)), B, HW, C, G,
+              float(eps), int(silu), _stream())
+
+
+def groupnorm_bwd(X, dY, Radd, dX, gamma, beta, mean_rstd, dgamma, dbeta, coef, scratch, B, HW, C, G, silu):
+    x, ldx = _mat(X, BF16, 'X')
+    dy, lddy = _mat(dY, BF16, 'dY')
+    dx, lddx = _mat(dX, BF16, 'dX')
+    r, ldr = _mat(Radd, BF16, 'Radd') if Radd is not None else (0, 0)
+    for t in (X, dY, dX) + ((Radd,) if Radd is not None else ()):
+        if tuple(t.shape) != (B * HW, C):
+            raise ValueError('groupnorm_bwd: bad shapes')
+    _lib.call('da_groupnorm_bwd', x, ldx, dy, lddy, r, ldr, dx, lddx, _vec(gamma, C), _vec(beta, C),
+              _f32buf(mean_rstd, B * G * 2), _vec(dgamma, C), _vec(dbeta, C), _f32buf(coef, B * G * 2),
+              _f32buf(scratch, norm_scratch_floats(B, HW, C)), B, HW, C, G, int(silu), _stream())
+
+
+def layernorm_fwd(X, Y, gamma, beta, mean_rstd, eps=1e-5):
+    x, ldx = _mat(X, BF16, 'X')
+    y, ldy = _mat(Y, BF16, 'Y')
+    M, C = X.shape
+    _lib.call('da_layernorm_fwd', x, ldx, y, ldy, _vec(gamma, C), _vec(beta, C), _f32buf(mean_rstd, 2 * M), M, C,
+              float(eps), _stream())
+
+
+def layernorm_bwd(X, dY, Radd, dX, gamma, mean_rstd, dgamma, dbeta, scratch):
+    x, ldx = _mat(X, BF16, 'X')
+    dy, lddy = _mat(dY, BF16, 'dY')
+    dx, lddx = _mat(dX, BF16, 'dX')
+    r, ldr = _mat(Radd, BF16, 'Radd') if Radd is not None else (0, 0)
+    M, C = X.shape
+    _lib.call('da_layernorm_bwd', x, ldx, dy, lddy, r, ldr, dx, lddx, _vec(gamma, C), _f32buf(mean_rstd, 2 * M),
+              _vec(dgamma, C), _vec(dbeta, C), _f32buf(scratch, 256 * C * 2), M, C, _stream())
+
+
+def colsum_accum(X, out, scratch):
+    x, ldx = _mat(X, BF16, 'X')
+    M, C = X.shape
+    _lib.call('da_colsum_accum', x, ldx, _vec(out, C), _f32buf(scratch, 256 * C * 2), M, C, _stream())
+
+
+def image_colsum(X, out, db, scratch, B, HW):
+    x, ldx = _mat(X, BF16, 'X')
+    o, ldo = _mat(out, BF16, 'out')
+    C = X.shape[1]
+    if tuple(out.shape) != (B, C) or X.shape[0] != B * HW:
+        raise ValueError('image_colsum: bad shapes')
+    _lib.call('da_image_colsum', x, ldx, o, ldo, _vec(db, C) if db is not None else 0,
+              _f32buf(scratch, norm_scratch_floats(B, HW, C)), B, HW, C, _stream())
+
+
+def geglu_fwd(inp, out):
+    i, ldi = _mat(inp, BF16)
+    o, ldo = _mat(out, BF16)
+    M, C2 = inp.shape
+    _lib.call('da_geglu_fwd', i, ldi, o, ldo, M, C2 // 2, _stream())
+
+
+def geglu_bwd(inp, dout, din):
+    i, ldi = _mat(inp, BF16)
+    d, ldd = _mat(dout, BF16)
+    di, lddi = _mat(din, BF16)
+    M, C2 = inp.shape
+    _lib.call('da_geglu_bwd', i, ldi, d, ldd, di, lddi, M, C2 // 2, _stream())
+
+
+def silu_fwd(x, y):
+    a, lda = _mat(x, BF16)
+    b, ldb = _mat(y, BF16)
+    _lib.call('da_silu_fwd', a, lda, b, ldb, x.shape[0], x.shape[1], _stream())
+
+
+def silu_bwd(x, dy, dx):
+    a, lda = _mat(x, BF16)
+    b, ldb = _mat(dy, BF16)
+    c, ldc = _mat(dx, BF16)
+    _lib.call('da_silu_bwd', a, lda, b, ldb, c, ldc, x.shape[0], x.shape[1], _stream())
+
+
+def add(a, b, out):
+    pa, lda = _mat(a, BF16)
+    pb, ldb = _mat(b, BF16)
+    po, ldo = _mat(out, BF16)
+    if a.shape != b.shape or a.shape != out.shape:
+        raise ValueError('add: shape mismatch')
+    _lib.call('da_add', pa, lda, pb, ldb, po, ldo, a.shape[0], a.shape[1], _stream())
+    return out
+
+
+def copy2d(a, out):
+    pa, lda = _mat(a, BF16)
+    po, ldo = _mat(out, BF16)
+    if a.shape != out.shape:
+        raise ValueError('copy2d: shape mismatch')
+    _lib.call('da_copy2d', pa, lda, po, ldo, a.shape[0], a.shape[1], _stream())
+    return out
+
+
+def upsample2x_bwd(dy, dx, B, H, W, C):
+    if not (dy.is_contiguous() and dx.is_contiguous()) or dy.numel() != 4 * B * H * W * C or dx.numel() != B * H * W * C:
+        raise ValueError('upsample2x_bwd: bad shapes')
+    _lib.call('da_upsample2x_bwd', dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream())
+
+
+def upsample2x_fwd(x, y, B, H, W, C):
+    if not (x.is_contiguous() and y.is_contiguous()) or y.numel() != 4 * B * H * W * C or x.numel() != B * H * W * C:
+        raise ValueError('upsample2x_fwd: bad shapes')
+    _lib.call('da_upsample2x_fwd', x.data_ptr(), y.data_ptr(), B, H, W, C, _stream())
+
+
+def timestep_embed(t, out):
+    if t.dtype != torch.int64 or not t.is_contiguous() or out.dtype != BF16 or not out.is_contiguous():
+        raise ValueError('timestep_embed: t int64 contiguous, out bf16 contiguous')
+    _lib.call('da_timestep_embed', t.data_ptr(), out.data_ptr(), t.numel(), out.shape[1], _stream())
+
+
+def add_noise(x0, eps, t, sqrt_ac, sqrt_1mac, xt, target, v_pred):
+    B = x0.shape[0]
+    HW = x0.shape[2] * x0.shape[3]
+    for z in (x0, eps):
+        if z.dtype != F32 or not z.is_contiguous() or z.shape[1] != 4 or z.shape != x0.shape:
+            raise ValueError('add_noise: x0/eps must be contiguous fp32 [B,4,H,W]')
+    if xt.dtype != BF16 or xt.numel() != B * HW * 8 or target.dtype != F32 or target.numel() != B * HW * 8:
+        raise ValueError('add_noise: xt bf16 [B*HW,8], target fp32 [B*HW,8]')
+    if int(sqrt_ac.numel()) != int(sqrt_1mac.numel()):
+        raise ValueError('add_noise: table mismatch')
+    _lib.call('da_add_noise', x0.data_ptr(), eps.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(),
+              xt.data_ptr(), target.data_ptr(), B, HW, int(v_pred), _stream())
+
+
+def mse_loss(pred, target, dpred, loss, scratch, total_pix, grad_coef, weight, accumulate):
+    if pred.dtype != F32 or target.dtype != F32 or dpred.dtype != BF16:
+        raise ValueError('mse_loss: dtypes')
+    if pred.numel() != total_pix * 8 or target.numel() != total_pix * 8 or dpred.numel() != total_pix * 8:
+        raise ValueError('mse_loss: sizes')
+    _lib.call('da_mse_loss', pred.data_ptr(), target.data_ptr(), dpred.data_ptr(), loss.data_ptr(),
+              _f32buf(scratch, 1024), total_pix, float(grad_coef), float(weight), int(accumulate), _stream())
+
+
+def adamw(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, grad_scale):
+    n = p.numel()
+    for z in (p, g, m, v):
+        if z.dtype != F32 or not z.is_contiguous() or z.numel() != n:
+            raise ValueError('adamw: fp32 contiguous flat buffers of equal size required')
+    if shadow.dtype != BF16 or shadow.numel() != n:
+        raise ValueError('adamw: shadow')
+    _lib.call('da_adamw', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(), n, float(lr),
+              float(beta1), float(beta2), float(eps), float(wd), int(step), float(grad_scale), _stream())
+
+
+def cast_f32_bf16(src, dst):
+    if src.dtype != F32 or dst.dtype != BF16 or src.numel() != dst.numel() or not src.is_contiguous():
+        raise ValueError('cast: bad args')
+    _lib.call('da_cast_f32_bf16', src.data_ptr(), dst.data_ptr(), src.numel(), _stream())
+
+
+def transpose_weight(src, dst, N, T, C):
+    if src.dtype != BF16 or dst.dtype != BF16 or src.numel() != N * T * C or dst.numel() != N * T * C:
+        raise ValueError('transpose_weight: bad args')
+    _lib.call('da_transpose_weight', src.data_ptr(), dst.data_ptr(), N, T, C, _stream())

@@ -1,0 +1,135 @@
+/* diffusion_amd.h - C ABI of libdiffusion_amd.so: the MI355X (gfx950) kernels behind the Stable Diffusion 2
+ * U-Net training step.
+ *
+ * Boundary contract.  The reference (fanzhongyi/diffusion) is pure Python and has no
+ * FFI of its own: its hot path enters native code through torch / diffusers / xformers calls made from
+ *   diffusion/models/stable_diffusion.py:177-183   (timestep draw, add_noise, unet(...)['sample'])
+ *   diffusion/models/stable_diffusion.py:185-187   (F.mse_loss)
+ *   diffusion/train.py:33 + yamls/hydra-yamls/SD-2-base-256.yaml:55-58  (torch.optim.AdamW)
+ *   diffusion/models/models.py:109-111             (xformers memory-efficient attention)
+ *   diffusion/train.py:91-108                      (Composer low-precision GroupNorm / LayerNorm)
+ * Every entry point below replaces one of those native ops; the comment on each names the call site.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless said otherwise
+ *   - activations are bf16, "NHWC": a tensor [B,H,W,C] is a row-major matrix [B*H*W rows][C] whose row
+ *     stride (ld*, in ELEMENTS) may exceed C, so column slices of wider buffers (fused QKV, concat) are
+ *     addressed without copies.  C, ld* and every column offset are multiples of 8 (16-byte vectors).
+ *   - statistics, biases, norm affine parameters, master weights and gradients are fp32
+ *   - no hidden allocation, no host synchronisation: scratch buffers are passed in, work is enqueued on
+ *     `stream` (a hipStream_t) and the call returns immediately; safe under hipGraph stream capture
+ *   - return value: 0 ok, DA_ERR_SHAPE (1) rejected arguments (nothing launched), DA_ERR_LAUNCH (2) HIP error
+ */
+#ifndef DIFFUSION_AMD_H
+#define DIFFUSION_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* da_stream_t; /* == hipStream_t */
+
+/* C[M,N] = alpha * gather(A)[M,K] . W[N,K]^T (+bias[N]) (+rowbias[image(m)][N]) (+R[M,N]).
+ * Replaces torch.nn.Conv2d 3x3/1x1 (cuDNN) and torch.nn.Linear (cuBLAS) inside diffusers ResnetBlock2D /
+ * Transformer2DModel, reached from stable_diffusion.py:183; with the transposed weight shadow it is also
+ * their dgrad in backward.  K = ksize*ksize*Cin; W is [N][kh][kw][Cin]; M = B*Hout*Wout.
+ * mode 0: stride 1 (pad 1 when ksize 3); 1: stride 2 pad 1 (Downsample2D); 2: dgrad of mode 1 (A = dY at
+ * Hin x Win = half resolution); 3: 3x3 conv over the nearest-2x upsampled A (Upsample2D), Hout = 2*Hin.
+ * out_fp32: C is float* (else bf16). */
+int da_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const void* rowbias,
+               long ldrb, const void* R, long ldr, int M, int N, int K, int Cin, int Hin, int Win, int Hout, int Wout,
+               int ksize, int mode, int out_fp32, float alpha, da_stream_t stream);
+
+/* dW[N][ksize*ksize*Cin] += sum_m dY[m][n] * gather(X)[m][k]   (fp32, atomically accumulated).
+ * Replaces the cuDNN/cuBLAS wgrad kernels autograd runs for the same layers (loss.backward() driven by
+ * Composer).  modes 0, 1, 3 as above. */
+int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, int M, int N, int Cin, int Hin,
+                     int Win, int Hout, int Wout, int ksize, int mode, da_stream_t stream);
+
+/* softmax(Q K^T * scale) V for head_dim 64, heads at column offsets h*64 of Q/K/V/O; L2[B][H][Nq] receives the
+ * per-row log2-sum-exp.  Replaces xformers memory_efficient_attention (models.py:109-111) / diffusers
+ * attention for attn1 (self) and attn2 (cross, Nk = 77). */
+int da_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O, long ldo,
+                float* L2, int B, int H, int Nq, int Nk, float scale, da_stream_t stream);
+/* backward of the above; Delta[B][H][Nq] is scratch (rowsum(dO*O)). */
+int da_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const void* O, long ldo,
+                const void* dO, long lddo, const float* L2, float* Delta, void* dQ, long lddq, void* dK, long lddk,
+                void* dV, long lddv, int B, int H, int Nq, int Nk, float scale, da_stream_t stream);
+
+/* floats of scratch the norm / colsum entry points need for (B, HW, C) */
+long da_norm_scratch_floats(int B, int HW, int C);
+
+/* GroupNorm (+ optional fused SiLU) over [B][HW][C], G groups.  Replaces torch.nn.GroupNorm / Composer
+ * LPGroupNorm (train.py:91-99) + F.silu in ResnetBlock2D / Transformer2DModel / conv_norm_out.
+ * mean_rstd[B][G][2] is saved for backward; scale_shift[B][C][2] is scratch. */
+int da_groupnorm_fwd(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta,
+                     float* mean_rstd, float* scale_shift, float* scratch, int B, int HW, int C, int G, float eps,
+                     int silu, da_stream_t stream);
+/* dX = GN(+SiLU) backward (+ Radd if non-null); dgamma/dbeta accumulated (+=); coef[B][G][2] scratch. */
+int da_groupnorm_bwd(const void* X, long ldx, const void* dY, long lddy, const void* Radd, long ldr, void* dX,
+                     long lddx, const float* gamma, const float* beta, const float* mean_rstd, float* dgamma,
+                     float* dbeta, float* coef, float* scratch, int B, int HW, int C, int G, int silu,
+                     da_stream_t stream);
+
+/* LayerNorm over rows of C.  Replaces torch.nn.LayerNorm / Composer LPLayerNorm (train.py:100-108) in
+ * BasicTransformerBlock.  mean_rstd[M][2] saved for backward. */
+int da_layernorm_fwd(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta,
+                     float* mean_rstd, int M, int C, float eps, da_stream_t stream);
+int da_layernorm_bwd(const void* X, long ldx, const void* dY, long lddy, const void* Radd, long ldr, void* dX,
+                     long lddx, const float* gamma, const float* mean_rstd, float* dgamma, float* dbeta,
+                     float* scratch, int M, int C, da_stream_t stream);
+
+/* out[c] += sum_m X[m][c]  (bias gradients of every conv / linear) */
+int da_colsum_accum(const void* X, long ldx, float* out, float* scratch, int M, int C, da_stream_t stream);
+
+/* out[b][c] = sum over the HW pixels of image b of X (bf16, row stride ldo) and db[c] += sum_b out[b][c]:
+ * gradient of the broadcast timestep-FiLM add (h + time_emb_proj(temb)[:, :, None, None]) and of conv1's bias. */
+int da_image_colsum(const void* X, long ldx, void* out, long ldo, float* db, float* scratch, int B, int HW, int C,
+                    da_stream_t stream);
+
+/* GEGLU feed-forward gate: in = [a | g] (2*Cout columns), out = a * gelu_erf(g).  Replaces diffusers GEGLU. */
+int da_geglu_fwd(const void* in, long ldi, void* out, long ldo, int M, int Cout, da_stream_t stream);
+int da_geglu_bwd(const void* in, long ldi, const void* dout, long lddo, void* din, long lddi, int M, int Cout,
+                 da_stream_t stream);
+
+/* SiLU on the timestep embedding (ResnetBlock2D nonlinearity(temb), TimestepEmbedding act) */
+int da_silu_fwd(const void* x, long ldx, void* y, long ldy, int M, int C, da_stream_t stream);
+int da_silu_bwd(const void* x, long ldx, const void* dy, long lddy, void* dx, long lddx, int M, int C,
+                da_stream_t stream);
+
+/* strided add / copy: residual gradient sums and torch.cat([h, skip], dim=1) of the up blocks */
+int da_add(const void* a, long lda, const void* b, long ldb, void* o, long ldo, int M, int C, da_stream_t stream);
+int da_copy2d(const void* a, long lda, void* o, long ldo, int M, int C, da_stream_t stream);
+
+/* nearest-neighbour 2x upsample of [B,H,W,C] (diffusers Upsample2D / F.interpolate) and its backward */
+int da_upsample2x_fwd(const void* x, void* y, int B, int H, int W, int C, da_stream_t stream);
+int da_upsample2x_bwd(const void* dy, void* dx, int B, int H, int W, int C, da_stream_t stream);
+
+/* diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0): out[B][dim] = [cos | sin] (bf16); t is int64 */
+int da_timestep_embed(const long long* t, void* out, int B, int dim, da_stream_t stream);
+
+/* DDPMScheduler.add_noise (stable_diffusion.py:180) fused with the NCHW fp32 -> NHWC(8) bf16 relayout and
+ * the training target (eps, or get_velocity when v_pred - pixel_diffusion.py:90-91).
+ * x0, eps: [B][4][HW] fp32; xt: [B*HW][8] bf16 (channels 4..7 zero); target: [B*HW][8] fp32. */
+int da_add_noise(const float* x0, const float* eps, const long long* t, const float* sqrt_ac,
+                 const float* sqrt_1mac, void* xt, float* target, int B, int HW, int v_pred, da_stream_t stream);
+
+/* F.mse_loss(pred, target) (stable_diffusion.py:187) over the 4 valid channels of NHWC(8) fp32 tensors and its
+ * gradient dpred = grad_coef * (pred - target) (bf16, NHWC(8)).  loss[0] (+)= weight * mean.  scratch >= 1024 floats */
+int da_mse_loss(const float* pred, const float* target, void* dpred, float* loss, float* scratch, long total_pix,
+                float grad_coef, float weight, int accumulate, da_stream_t stream);
+
+/* torch.optim.AdamW step (train.py:33; SD-2-base-256.yaml:55-58) on flat fp32 master/moment buffers, gradient
+ * pre-scaled by grad_scale; also writes the bf16 compute shadow. */
+int da_adamw(float* p, const float* g, float* m, float* v, void* shadow, long n, float lr, float beta1, float beta2,
+             float eps, float wd, int step, float grad_scale, da_stream_t stream);
+
+int da_cast_f32_bf16(const float* src, void* dst, long n, da_stream_t stream);
+
+/* dst[c][T-1-t][n] = src[n][t][c]: the weight layout da_gemm_nt needs for dgrad */
+int da_transpose_weight(const void* src, void* dst, int N, int T, int C, da_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
