@@ -29,11 +29,16 @@ template <int MODE>
 __global__ void chan_reduce_kernel(ChanReduceParams p) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int tid = threadIdx.x;
-  const int nvec = p.C >> 3;
-  const int vec = tid % nvec, pl = tid / nvec;
+  // channels are split over blockIdx.z in slabs of <= 512 vectors (4096 channels)
+  const int vec0 = blockIdx.z * 512;
+  const int nvec = min(512, (p.C >> 3) - vec0);
+  const int Cb = nvec * 8;
+  const int lvec = tid % nvec, pl = tid / nvec;
+  const int vec = vec0 + lvec;
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int p0 = chunk * p.ppc;
   const int p1 = min(p.HW, p0 + p.ppc);
+  const bool active = pl < p.pxt;
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -49,43 +54,45 @@ __global__ void chan_reduce_kernel(ChanReduceParams p) {
       be[e] = p.beta[c];
     }
   }
-  for (int pix = p0 + pl; pix < p1; pix += p.pxt) {
-    const long row = (long)b * p.HW + pix;
-    bf16x8 x = ld8(p.X + row * p.ldx + 8 * vec);
-    if (MODE == 0) {
+  if (active) {
+    for (int pix = p0 + pl; pix < p1; pix += p.pxt) {
+      const long row = (long)b * p.HW + pix;
+      bf16x8 x = ld8(p.X + row * p.ldx + 8 * vec);
+      if (MODE == 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = bf2f(x[e]);
-        s1[e] += v;
-        s2[e] += v * v;
+        for (int e = 0; e < 8; ++e) {
+          float v = bf2f(x[e]);
+          s1[e] += v;
+          s2[e] += v * v;
+        }
+      } else if (MODE == 1) {
+        bf16x8 dy = ld8(p.DY + row * p.lddy + 8 * vec);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xh = (bf2f(x[e]) - mu[e]) * rs[e];
+          float dz = bf2f(dy[e]);
+          if (p.silu) dz *= dsilu_f(xh * ga[e] + be[e]);
+          s1[e] += dz;
+          s2[e] += dz * xh;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[e] += bf2f(x[e]);
       }
-    } else if (MODE == 1) {
-      bf16x8 dy = ld8(p.DY + row * p.lddy + 8 * vec);
+    }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float xh = (bf2f(x[e]) - mu[e]) * rs[e];
-        float dz = bf2f(dy[e]);
-        if (p.silu) dz *= dsilu_f(xh * ga[e] + be[e]);
-        s1[e] += dz;
-        s2[e] += dz * xh;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s1[e] += bf2f(x[e]);
+    for (int e = 0; e < 8; ++e) {
+      red[((long)pl * Cb + 8 * lvec + e) * 2] = s1[e];
+      red[((long)pl * Cb + 8 * lvec + e) * 2 + 1] = s2[e];
     }
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    red[((long)pl * p.C + 8 * vec + e) * 2] = s1[e];
-    red[((long)pl * p.C + 8 * vec + e) * 2 + 1] = s2[e];
-  }
   __syncthreads();
-  float* out = p.partial + ((long)b * p.nchunks + chunk) * p.C * 2;
-  for (int c = tid; c < p.C; c += blockDim.x) {
+  float* out = p.partial + (((long)b * p.nchunks + chunk) * p.C + 8 * vec0) * 2;
+  for (int c = tid; c < Cb; c += blockDim.x) {
     float a = 0.f, q = 0.f;
     for (int k = 0; k < p.pxt; ++k) {
-      a += red[((long)k * p.C + c) * 2];
-      q += red[((long)k * p.C + c) * 2 + 1];
+      a += red[((long)k * Cb + c) * 2];
+      q += red[((long)k * Cb + c) * 2 + 1];
     }
     out[c * 2] = a;
     out[c * 2 + 1] = q;
@@ -93,15 +100,19 @@ __global__ void chan_reduce_kernel(ChanReduceParams p) {
 }
 
 int launch_chan_reduce(int mode, ChanReduceParams& p, int B, hipStream_t stream) {
-  const int nvec = p.C >> 3;
-  if (nvec < 1 || nvec > 512) return DA_ERR_SHAPE;
+  const int nvec_total = p.C >> 3;
+  if (nvec_total < 1) return DA_ERR_SHAPE;
+  const int zsplit = (nvec_total + 511) / 512;
+  // every z-slab uses the same pxt, sized for the widest slab
+  const int nvec = nvec_total < 512 ? nvec_total : 512;
   int pxt = 512 / nvec;
   if (pxt > p.HW) pxt = p.HW;
   if (pxt < 1) pxt = 1;
   p.pxt = pxt;
   p.ppc = (p.HW + p.nchunks - 1) / p.nchunks;
-  const size_t smem = (size_t)pxt * p.C * 2 * sizeof(float);
-  dim3 grid(p.nchunks, B), block(nvec * pxt);
+  const size_t smem = (size_t)pxt * nvec * 8 * 2 * sizeof(float);
+  // the last slab may be narrower: its threads beyond nvec_last*pxt idle via the `active` predicate
+  dim3 grid(p.nchunks, B, zsplit), block(nvec * pxt);
   if (mode == 0) hipLaunchKernelGGL(chan_reduce_kernel<0>, grid, block, smem, stream, p);
   else if (mode == 1) hipLaunchKernelGGL(chan_reduce_kernel<1>, grid, block, smem, stream, p);
   else hipLaunchKernelGGL(chan_reduce_kernel<2>, grid, block, smem, stream, p);

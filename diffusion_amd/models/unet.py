@@ -161,6 +161,8 @@ class UNetHIP(nn.Module):
         self._scratch = None
         self._scratch_key = None
         self.opt_step = 0
+        self._grad_ready_cb = None  # parallel.BucketedAllReducer.ready during the last microbatch
+        self._tape = None
         if init:
             self.reset_parameters(seed)
 
@@ -706,8 +708,11 @@ class UNetHIP(nn.Module):
         self._dtproj = self._bf(self._tproj.shape[0], self.tproj_total)
         dskip: Dict[int, torch.Tensor] = {}
         dh = None
+        off = lambda name: self.fp.storages[name].off
         for kind, sv in reversed(tape):
+            lo = None
             if kind == 'out':
+                lo = off('conv_norm_out.weight')
                 h, a, st, B, S = sv
                 m = self.M('conv_out.weight')
                 g3 = Geom.conv(B, S, S)
@@ -718,10 +723,13 @@ class UNetHIP(nn.Module):
                 dh = self._gn_bwd(h, da, None, 'conv_norm_out', st, B, S * S, 1)
             elif kind == 'resnet':
                 dh = self._resnet_bwd(sv, dh)
+                lo = off(sv[0] + '.norm1.weight')
             elif kind == 'transformer':
                 dh = self._transformer_bwd(sv, dh)
+                lo = off(sv[0] + '.norm.weight')
             elif kind == 'up':
                 key, x, B, r = sv
+                lo = off(key + '.weight')
                 m = self.M(key + '.weight')
                 ops.colsum_accum(dh, self.V(key + '.bias').g, self._scratch)
                 ops.gemm_tn_wgrad(dh, x, m.gw, Geom.up(B, r, r))
@@ -741,6 +749,7 @@ class UNetHIP(nn.Module):
                 dh = tot
             elif kind == 'down':
                 key, x, B, r = sv
+                lo = off(key + '.weight')
                 m = self.M(key + '.weight')
                 ops.colsum_accum(dh, self.V(key + '.bias').g, self._scratch)
                 ops.gemm_tn_wgrad(dh, x, m.gw, Geom.down(B, r, r))
@@ -753,8 +762,11 @@ class UNetHIP(nn.Module):
                 ops.add(dh, dskip.pop(0), tot)
                 ops.colsum_accum(tot, self.V('conv_in.bias').g, self._scratch)
                 ops.gemm_tn_wgrad(tot, xt8, self.M('conv_in.weight').gw, Geom.conv(B, S, S))
+                lo = off('conv_in.weight')
             else:  # pragma: no cover
                 raise AssertionError(kind)
+            if lo is not None and self._grad_ready_cb is not None:
+                self._grad_ready_cb(lo)
         # ---- timestep path
         te0, te1, te1s, temb, tembs = self._temb_saved
         Bt = te0.shape[0]

@@ -1,0 +1,47 @@
+"""Fused AdamW over the U-Net's flat buffers (one HIP launch for 866 M parameters).
+
+Stands where diffusion/train.py:33 instantiates ``torch.optim.AdamW`` from yamls/hydra-yamls/SD-2-base-256.yaml:55-58
+(lr 1e-4, weight_decay 0.01, torch-default betas/eps).  Same update rule as torch.optim.AdamW; additionally writes
+the bf16 compute shadow and refreshes the transposed (dgrad) shadow."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class FusedAdamW(torch.optim.Optimizer):
+
+    def __init__(self, params=None, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2, unet=None):
+        if unet is None:
+            raise ValueError('FusedAdamW needs the UNetHIP that owns the flat parameter buffers (unet=...)')
+        self.unet = unet
+        # torch.optim bookkeeping (param_groups / state_dict) over a single flat tensor
+        super().__init__([unet.master], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        u = self.unet
+        u.opt_step += 1
+        ops.adamw(u.master, u.grad, u.exp_avg, u.exp_avg_sq, u.shadow, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                  g['weight_decay'], u.opt_step, self.grad_scale)
+        u.refresh_transposed()
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.unet.grad.zero_()
+
+    def state_dict(self):
+        u = self.unet
+        return {'step': u.opt_step, 'exp_avg': u.exp_avg, 'exp_avg_sq': u.exp_avg_sq,
+                'param_groups': [{k: v for k, v in self.param_groups[0].items() if k != 'params'}]}
+
+    def load_state_dict(self, sd):
+        u = self.unet
+        u.opt_step = int(sd['step'])
+        u.exp_avg.copy_(sd['exp_avg'])
+        u.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        for k, v in sd['param_groups'][0].items():
+            self.param_groups[0][k] = v

@@ -1,0 +1,186 @@
+"""Minimal trainer with the slice of ``composer.Trainer`` the reference configures
+(yamls/hydra-yamls/SD-2-base-256.yaml:82-96, built at diffusion/train.py:118-128, run at :130-138):
+``max_duration`` in batches, ``device_train_microbatch_size`` gradient accumulation, LR schedule, callbacks
+(SpeedMonitor = the source of the README's images/sec), checkpoint save/load.  Precision is bf16 inside the
+kernels (the reference's ``amp_fp16`` + GradScaler has no counterpart: bf16 needs no loss scaling)."""
+from __future__ import annotations
+
+import os
+import time
+from typing import Any, Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .optim import FusedAdamW
+from .parallel import BucketedAllReducer
+
+
+def _parse_time(s, default_unit='ba'):
+    if isinstance(s, int):
+        return s, default_unit
+    s = str(s)
+    for unit in ('ba', 'ep', 'sp', 'dur'):
+        if s.endswith(unit):
+            return float(s[:-len(unit)]) if unit == 'dur' else int(s[:-len(unit)]), unit
+    return int(s), default_unit
+
+
+class MultiStepWithWarmupScheduler:
+    """composer.optim.MultiStepWithWarmupScheduler: linear warm-up over t_warmup then x gamma at each milestone."""
+
+    def __init__(self, t_warmup='0ba', milestones=(), gamma: float = 0.1, scale_warmup: bool = False):
+        self.t_warmup = _parse_time(t_warmup)
+        self.milestones = [_parse_time(m) for m in milestones]
+        self.gamma = gamma
+
+    def __call__(self, batch_idx: int, batches_per_epoch: Optional[int] = None) -> float:
+        w, unit = self.t_warmup
+        if unit == 'ep':
+            w = w * (batches_per_epoch or 0)
+        if w and batch_idx < w:
+            return batch_idx / w
+        f = 1.0
+        for m, unit in self.milestones:
+            mb = m * batches_per_epoch if (unit == 'ep' and batches_per_epoch) else (m if unit == 'ba' else None)
+            if mb is not None and batch_idx >= mb:
+                f *= self.gamma
+        return f
+
+
+class Callback:
+
+    def batch_end(self, trainer):
+        pass
+
+    def fit_end(self, trainer):
+        pass
+
+
+class SpeedMonitor(Callback):
+    """samples/sec over a sliding window of batches (composer.callbacks.SpeedMonitor, window_size=10 in the YAML)."""
+
+    def __init__(self, window_size: int = 10, **kw):
+        self.window = window_size
+        self.times: List[float] = []
+        self.throughput = None
+
+    def batch_end(self, trainer):
+        torch.cuda.synchronize()
+        self.times.append(time.perf_counter())
+        if len(self.times) > self.window + 1:
+            self.times.pop(0)
+        if len(self.times) > 1:
+            dt = self.times[-1] - self.times[0]
+            self.throughput = (len(self.times) - 1) * trainer.global_batch_size / dt
+            trainer.log({'throughput/samples_per_sec': self.throughput})
+
+
+class NoOpCallback(Callback):
+    """LRMonitor / MemoryMonitor / RuntimeEstimator / OptimizerMonitor / loggers: observability, out of scope."""
+
+    def __init__(self, *a, **kw):
+        pass
+
+
+class Trainer:
+
+    def __init__(self, model, train_dataloader: Iterable, optimizers=None, max_duration='1ba',
+                 device_train_microbatch_size: Optional[int] = None, schedulers=None, callbacks=None, loggers=None,
+                 algorithms=None, eval_dataloader=None, eval_interval=None, device='gpu', run_name=None, seed=None,
+                 scale_schedule_ratio: float = 1.0, save_folder=None, save_interval=None, save_overwrite=True,
+                 autoresume=False, fsdp_config=None, precision=None, log_every: int = 10, **unused):
+        self.model = model
+        self.dataloader = train_dataloader
+        self.optimizer: FusedAdamW = optimizers
+        self.max_batches, unit = _parse_time(max_duration)
+        if unit != 'ba':
+            raise ValueError('max_duration must be given in batches (e.g. 550000ba)')
+        self.microbatch = device_train_microbatch_size
+        self.scheduler = schedulers
+        self.callbacks: List[Callback] = [c for c in (callbacks or []) if isinstance(c, Callback)]
+        self.save_folder = save_folder
+        self.save_interval = _parse_time(save_interval)[0] if save_interval else None
+        self.batch_idx = 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.reducer = BucketedAllReducer(model.unet.grad)
+        self.base_lr = self.optimizer.param_groups[0]['lr']
+        self.global_batch_size = None
+        self.logs: List[dict] = []
+        self.log_every = log_every
+
+    def log(self, d):
+        d = dict(d, batch=self.batch_idx)
+        self.logs.append(d)
+        if self.rank == 0 and self.batch_idx % self.log_every == 0:
+            print(' '.join(f'{k}={v:.6g}' if isinstance(v, float) else f'{k}={v}' for k, v in d.items()), flush=True)
+
+    def train_batch(self, batch) -> torch.Tensor:
+        """One optimizer step: microbatched forward/backward, gradient all-reduce, fused AdamW."""
+        model, unet = self.model, self.model.unet
+        n = next(v.shape[0] for v in batch.values() if torch.is_tensor(v))
+        self.global_batch_size = n * self.world
+        mb = self.microbatch or n
+        unet.zero_grad()
+        total = torch.zeros((), device=unet.device_)
+        starts = list(range(0, n, mb))
+        self.reducer.begin()
+        for i, s in enumerate(starts):
+            sub = {k: (v[s:s + mb] if torch.is_tensor(v) else v) for k, v in batch.items()}
+            w = min(mb, n - s) / n
+            outputs = model(sub)
+            loss = model.loss(outputs, sub, weight=w)
+            unet._grad_ready_cb = self.reducer.ready if i == len(starts) - 1 else None
+            model.backward_from_loss()
+            for m in model.get_metrics(is_train=True).values():
+                model.update_metric(sub, outputs, m)
+            total = total + loss.detach() * w
+        unet._grad_ready_cb = None
+        self.reducer.flush()
+        if self.scheduler is not None:
+            bpe = len(self.dataloader) if hasattr(self.dataloader, '__len__') else None
+            self.optimizer.param_groups[0]['lr'] = self.base_lr * self.scheduler(self.batch_idx, bpe)
+        self.optimizer.grad_scale = 1.0 / self.world
+        self.optimizer.step()
+        return total
+
+    def fit(self):
+        it = iter(self.dataloader)
+        while self.batch_idx < self.max_batches:
+            try:
+                batch = next(it)
+            except StopIteration:
+                it = iter(self.dataloader)
+                batch = next(it)
+            dev = self.model.unet.device_
+            batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            loss = self.train_batch(batch)
+            self.batch_idx += 1
+            if self.batch_idx % self.log_every == 0 or self.batch_idx == self.max_batches:
+                self.log({'loss/train/total': float(loss.item())})
+            for c in self.callbacks:
+                c.batch_end(self)
+            if self.save_folder and self.save_interval and self.batch_idx % self.save_interval == 0:
+                self.save_checkpoint(os.path.join(self.save_folder, f'ba{self.batch_idx}-rank{self.rank}.pt'))
+        for c in self.callbacks:
+            c.fit_end(self)
+
+    def eval(self, subset_num_batches=None):  # evaluation (FID / sampling) is outside the hot path
+        return {}
+
+    # checkpoints keep the reference layout state['state']['model'] with diffusers key names under 'unet.'
+    def save_checkpoint(self, path):
+        if self.rank != 0:
+            return
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        unet = self.model.unet
+        torch.save({'state': {'model': {f'unet.{k}': v.detach().cpu().contiguous() for k, v in unet.state_dict().items()},
+                              'optimizers': self.optimizer.state_dict(), 'batch': self.batch_idx}}, path)
+
+    def load_checkpoint(self, path):
+        ck = torch.load(path, map_location='cpu')
+        sd = {k[len('unet.'):]: v for k, v in ck['state']['model'].items() if k.startswith('unet.')}
+        self.model.unet.load_state_dict(sd)
+        self.optimizer.load_state_dict(ck['state']['optimizers'])
+        self.batch_idx = ck['state']['batch']

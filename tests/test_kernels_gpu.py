@@ -285,6 +285,15 @@ def test_colsums(ops, dev):
     check(db, ref.sum(0), tol=1e-4, what='image colsum db')
 
 
+def test_colsum_wide(ops, dev):
+    for M, C in ((16, 10240), (300, 5120), (64, 4104)):
+        x = rnd(M, C, dev=dev, seed=1).to(BF)
+        out = torch.zeros(C, device=dev)
+        scratch = torch.empty(256 * C * 2, device=dev)
+        ops.colsum_accum(x, out, scratch)
+        check(out, x.float().sum(0), tol=1e-4, what=f'colsum wide {M}x{C}')
+
+
 # ------------------------------------------------------------------------------------------------ pointwise
 def test_geglu_silu_add_copy(ops, dev):
     M, C = 130, 640
