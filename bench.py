@@ -1,0 +1,162 @@
+"""bench.py - U-Net training throughput (images/sec) of the SD-2-base training step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N=1 default)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W            (one rank per GPU, RCCL)
+
+A "step" = one optimizer step over the per-GPU batch (BASELINE.json configs[1]: SD-2-base U-Net only, precomputed
+latents 4x32x32, batch 256 per GPU, bf16): microbatched forward + fused MSE + backward of the 865.9 M-parameter U-Net,
+gradient all-reduce over RCCL (N>1) overlapped with the last microbatch's backward, fused AdamW.  Weak scaling: the
+per-GPU batch is fixed, global batch = 256*N (2048 at N=8 = the reference's configuration).  Inputs (fp16 latents and
+text embeddings, as the reference dataloader yields them) are resident in HBM before the timed region; timestep and
+noise draws are inside it, as in the reference's forward.  Weights are torch-default random init (seed 17).
+Prints ONE JSON line on rank 0 (see README / task contract), including `roofline` for the dominant kernel
+(gemm_nt_kernel: all conv / linear forward + dgrad contractions) and a `cpu_baseline` (oracle port on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TRAIN_GFLOP_PER_IMG = {32: 543.27, 64: 2412.77, 96: 6447.32}  # fwd+dgrad+wgrad, 2*MAC
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+README_8xA100 = {32: 1100.0, 64: 290.0}  # /root/reference README.md:56 (8xA100, global batch 2048)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Oracle (CPU port of the same training step, fp32) on the host cores: bounded sample of cfg 1."""
+    from oracle import unet_oracle as O
+    cfg = O.UNetConfig.sd2_base()
+    torch.manual_seed(17)
+    sd = {}
+    for k, shape in O.param_manifest(cfg):  # fast init: statistics as init_state_dict, cheaper RNG
+        if 'norm' in k.rsplit('.', 2)[-2]:
+            sd[k] = torch.ones(shape) if k.endswith('weight') else torch.zeros(shape)
+        else:
+            fan = max(1, int(torch.tensor(shape[1:]).prod().item())) if len(shape) > 1 else shape[0]
+            sd[k] = (torch.rand(shape) * 2 - 1) / fan**0.5
+    B, S = 1, 32
+    g = torch.Generator().manual_seed(17)
+    lat = torch.randn(B, 4, S, S, generator=g)
+    ctx = torch.randn(B, 77, 1024, generator=g)
+    noise = torch.randn(B, 4, S, S, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        loss, _, grads = O.training_loss_and_grads(sd, cfg, lat, t, ctx, noise)
+        k0 = 'conv_in.weight'
+        O.adamw_step(sd[k0], grads[k0], torch.zeros_like(sd[k0]), torch.zeros_like(sd[k0]), 1, 1e-4)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget * 0.5 or n >= 3:
+            break
+    return {'value': round(B * n / el, 4), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} step(s) of SD-2-base U-Net fwd+bwd at batch {B} (4x32x32 latents, fp32, oracle/unet_oracle.py), '
+                      f'{el:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--latent', type=int, default=32, help='latent side: 32 (256 px), 64 (512 px), 96 (768 px v-pred)')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 256 @32, 64 @64, 16 @96)')
+    ap.add_argument('--microbatch', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    a = ap.parse_args()
+
+    from diffusion_amd.parallel import init_distributed_from_env
+    rank, local, world = init_distributed_from_env()
+    if world != a.gpus:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}')
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    from diffusion_amd import ops
+    from diffusion_amd.models.models import stable_diffusion_2
+    from diffusion_amd.optim import FusedAdamW
+    from diffusion_amd.trainer import Trainer
+
+    S = a.latent
+    B = a.batch or {32: 256, 64: 64, 96: 16}[S]
+    mb = a.microbatch or {32: 64, 64: 16, 96: 8}[S]
+    name = 'stabilityai/stable-diffusion-2' if S == 96 else 'stabilityai/stable-diffusion-2-base'
+    torch.manual_seed(17 + rank)
+    model = stable_diffusion_2(model_name=name, pretrained=False, precomputed_latents=True, fsdp=False, seed=17)
+    opt = FusedAdamW(lr=1e-4, weight_decay=0.01, unet=model.unet)
+    trainer = Trainer(model, train_dataloader=None, optimizers=opt, max_duration='1ba', device_train_microbatch_size=mb)
+    g = torch.Generator().manual_seed(1000 + rank)
+    batch = {'image_latents': torch.randn(B, 4, S, S, generator=g).half().to(dev),
+             'caption_latents': torch.randn(B, 77, 1024, generator=g).half().to(dev)}
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(a.warmup):
+        loss = trainer.train_batch(batch)
+    sync()
+    if not a.no_kernel_timing:
+        ops.PROFILE = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = trainer.train_batch(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    lossv = float(loss.item())
+
+    if rank == 0:
+        ips = B * world * a.steps / dt
+        out = {
+            'metric': f'U-Net training images/sec @{S * 8} (SD-2-base U-Net, precomputed latents 4x{S}x{S})',
+            'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(1000 * dt / a.steps, 2), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': (round(ips / README_8xA100[S], 3) if (world == 8 and S in README_8xA100) else None),
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'SD-2-base U-Net train step, latents 4x{S}x{S}, text 77x1024, batch {B}/GPU '
+                                   f'(global {B * world}), microbatch {mb}, AdamW, dp{world}',
+                       'global_batch': B * world, 'microbatch': mb, 'parallelism': f'dp{world}',
+                       'params': model.unet.num_params},
+            'loss': round(lossv, 5),
+            'step_tflops_per_gpu': round(ips / world * TRAIN_GFLOP_PER_IMG[S] / 1000, 1),
+            'step_frac_of_mfma_peak': round(ips / world * TRAIN_GFLOP_PER_IMG[S] / 1000 / PEAK_BF16_TFLOPS, 4),
+        }
+        if prof:
+            kern = {}
+            for k, evs in prof.items():
+                ms = sum(s.elapsed_time(e) for s, e, _ in evs)
+                fl = sum(f for _, _, f in evs)
+                kern[k] = {'launches': len(evs), 'ms': round(ms, 2), 'avg_us': round(1000 * ms / len(evs), 2),
+                           'tflops': round(fl / ms / 1e9, 1) if ms > 0 else None}
+            gk = kern['gemm_nt']
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel', 'achieved': gk['tflops'],
+                               'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(gk['tflops'] / PEAK_BF16_TFLOPS, 4),
+                               'avg_launch_us': gk['avg_us'], 'launches': gk['launches'], 'traffic': None}
+            out['kernels'] = kern
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -20,6 +20,29 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# bench.py instrumentation: when PROFILE is a dict, every launch of the named kernel family is bracketed by HIP
+# events on the launch stream and its algorithmic FLOPs are recorded: PROFILE[name] -> list of (start, end, flops)
+PROFILE = None
+
+
+class _Timed:
+    __slots__ = ('name', 'flops', 'start')
+
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            PROFILE.setdefault(self.name, []).append((self.start, end, self.flops))
+
+
 def _mat(x: torch.Tensor, dtype=BF16, name='arg') -> Tuple[int, int]:
     if x.dim() != 2 or x.stride(1) != 1 or x.dtype != dtype or not x.is_cuda:
         raise ValueError(f'{name}: need a 2-D {dtype} device matrix with unit column stride, got '
@@ -97,8 +120,10 @@ def gemm_nt(A, W, out, g: Geom, *, bias=None, rowbias=None, residual=None, alpha
         r_ptr, ldr = _mat(residual, BF16, 'residual')
         if tuple(residual.shape) != (M, N):
             raise ValueError('residual must be [M, N]')
-    _lib.call('da_gemm_nt', a_ptr, lda, w_ptr, c_ptr, ldc, _vec(bias, N, 'bias'), rb_ptr, ldrb, r_ptr, ldr, M, N, K,
-              Cin, g.Hin, g.Win, g.Hout, g.Wout, g.ksize, g.mode, int(out_fp32), float(alpha), _stream())
+    flops = 2.0 * M * N * K * (0.25 if g.mode == 2 else 1.0)  # mode 2: 3 of 4 taps are structurally zero
+    with _Timed('gemm_nt', flops):
+        _lib.call('da_gemm_nt', a_ptr, lda, w_ptr, c_ptr, ldc, _vec(bias, N, 'bias'), rb_ptr, ldrb, r_ptr, ldr, M, N,
+                  K, Cin, g.Hin, g.Win, g.Hout, g.Wout, g.ksize, g.mode, int(out_fp32), float(alpha), _stream())
     return out
 
 
@@ -115,8 +140,9 @@ def gemm_tn_wgrad(dY, X, dW, g: Geom):
     mode = g.mode
     if mode == 2:
         raise ValueError('wgrad has no mode 2')
-    _lib.call('da_gemm_tn_wgrad', dy_ptr, lddy, x_ptr, ldx, dW.data_ptr(), M, N, Cin, g.Hin, g.Win, g.Hout, g.Wout,
-              g.ksize, mode, _stream())
+    with _Timed('gemm_tn', 2.0 * M * N * g.ksize * g.ksize * Cin):
+        _lib.call('da_gemm_tn_wgrad', dy_ptr, lddy, x_ptr, ldx, dW.data_ptr(), M, N, Cin, g.Hin, g.Win, g.Hout,
+                  g.Wout, g.ksize, mode, _stream())
 
 
 def attn_fwd(Q, K, V, O, L2, B, H, Nq, Nk, scale):
@@ -127,8 +153,9 @@ def attn_fwd(Q, K, V, O, L2, B, H, Nq, Nk, scale):
     for t, n in ((Q, Nq), (O, Nq), (K, Nk), (V, Nk)):
         if tuple(t.shape) != (B * n, H * 64):
             raise ValueError(f'attention operand shape {tuple(t.shape)} != {(B * n, H * 64)}')
-    _lib.call('da_attn_fwd', q, ldq, k, ldk, v, ldv, o, ldo, _f32buf(L2, B * H * Nq, 'L2'), B, H, Nq, Nk,
-              float(scale), _stream())
+    with _Timed('attn_fwd', 4.0 * B * H * Nq * Nk * 64):
+        _lib.call('da_attn_fwd', q, ldq, k, ldk, v, ldv, o, ldo, _f32buf(L2, B * H * Nq, 'L2'), B, H, Nq, Nk,
+                  float(scale), _stream())
 
 
 def attn_bwd(Q, K, V, O, dO, L2, Delta, dQ, dK, dV, B, H, Nq, Nk, scale):
@@ -142,8 +169,9 @@ def attn_bwd(Q, K, V, O, dO, L2, Delta, dQ, dK, dV, B, H, Nq, Nk, scale):
         if tuple(t.shape) != (B * n, H * 64):
             raise ValueError(f'{nm} shape {tuple(t.shape)} != {(B * n, H * 64)}')
         outs += list(_mat(t, BF16, nm))
-    _lib.call('da_attn_bwd', *ptrs, _f32buf(L2, B * H * Nq, 'L2'), _f32buf(Delta, B * H * Nq, 'Delta'), *outs, B, H,
-              Nq, Nk, float(scale), _stream())
+    with _Timed('attn_bwd', 8.0 * B * H * Nq * Nk * 64):
+        _lib.call('da_attn_bwd', *ptrs, _f32buf(L2, B * H * Nq, 'L2'), _f32buf(Delta, B * H * Nq, 'Delta'), *outs, B,
+                  H, Nq, Nk, float(scale), _stream())
 
 
 def norm_scratch_floats(B, HW, C) -> int:
