@@ -56,6 +56,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: it bundles its own libamdhip64 (soname libamdhip64.so.7); loading ours before it
+    # would bring in /opt/rocm's copy as a SECOND HIP runtime, and torch-owned streams / pointers would be foreign to
+    # the runtime our kernels are launched through (every launch then fails with hipErrorInvalidResourceHandle).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NativeLibraryMissing(
             f'{LIB_PATH} not found: build it with `make -C diffusion_amd/csrc` (or __graft_entry__.build()). '

@@ -404,6 +404,7 @@ int check(long ld) { return (ld & 7) ? 1 : 0; }
 
 extern "C" int da_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
                            long ldo, float* L2, int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
+  DA_CLEAR_ERR();
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return DA_ERR_SHAPE;
   if (check(ldq) || check(ldk) || check(ldv) || check(ldo)) return DA_ERR_SHAPE;
   AttnParams p = {};
@@ -420,6 +421,7 @@ extern "C" int da_attn_bwd(const void* Q, long ldq, const void* K, long ldk, con
                            long ldo, const void* dO, long lddo, const float* L2, float* Delta, void* dQ, long lddq,
                            void* dK, long lddk, void* dV, long lddv, int B, int H, int Nq, int Nk, float scale,
                            hipStream_t stream) {
+  DA_CLEAR_ERR();
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return DA_ERR_SHAPE;
   if (check(ldq) || check(ldk) || check(ldv) || check(ldo) || check(lddo) || check(lddq) || check(lddk) ||
       check(lddv))

@@ -19,6 +19,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define DA_ERR_SHAPE 1
 #define DA_ERR_LAUNCH 2
 
+// hipGetLastError() is per-thread sticky-until-read: drop whatever an unrelated earlier runtime call left behind
+#define DA_CLEAR_ERR() (void)hipGetLastError()
+
 #define DA_CHECK_LAUNCH()                                   \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \

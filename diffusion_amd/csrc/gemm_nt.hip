@@ -240,6 +240,7 @@ extern "C" int da_gemm_nt(const void* A, long lda, const void* W, void* C, long 
                           const void* rowbias, long ldrb, const void* R, long ldr, int M, int N, int K, int Cin,
                           int Hin, int Win, int Hout, int Wout, int ksize, int mode, int out_fp32, float alpha,
                           hipStream_t stream) {
+  DA_CLEAR_ERR();
   if (M <= 0 || N <= 0 || K <= 0) return DA_ERR_SHAPE;
   if ((N & 7) || (Cin & 7) || (K % Cin) || (lda & 7) || (ldc & 7)) return DA_ERR_SHAPE;
   if (ksize != 1 && ksize != 3) return DA_ERR_SHAPE;

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNParams p) {
 
 extern "C" int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, int M, int N, int Cin,
                                 int Hin, int Win, int Hout, int Wout, int ksize, int mode, hipStream_t stream) {
+  DA_CLEAR_ERR();
   if (M <= 0 || N <= 0 || Cin <= 0) return DA_ERR_SHAPE;
   if ((N & 7) || (Cin & 7) || (lddy & 7) || (ldx & 7)) return DA_ERR_SHAPE;
   if (ksize != 1 && ksize != 3) return DA_ERR_SHAPE;

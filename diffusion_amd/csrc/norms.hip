@@ -422,6 +422,7 @@ extern "C" long da_norm_scratch_floats(int B, int HW, int C) {
 extern "C" int da_groupnorm_fwd(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta,
                                 float* mean_rstd, float* scale_shift, float* scratch, int B, int HW, int C, int G,
                                 float eps, int silu, hipStream_t stream) {
+  DA_CLEAR_ERR();
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 7) || (ldx & 7) || (ldy & 7)) return DA_ERR_SHAPE;
   ChanReduceParams p = {};
   p.X = (const bf16*)X; p.ldx = ldx; p.partial = scratch;
@@ -444,6 +445,7 @@ extern "C" int da_groupnorm_bwd(const void* X, long ldx, const void* dY, long ld
                                 void* dX, long lddx, const float* gamma, const float* beta, const float* mean_rstd,
                                 float* dgamma, float* dbeta, float* coef, float* scratch, int B, int HW, int C, int G,
                                 int silu, hipStream_t stream) {
+  DA_CLEAR_ERR();
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7))
     return DA_ERR_SHAPE;
   if (Radd && (ldr & 7)) return DA_ERR_SHAPE;
@@ -472,6 +474,7 @@ extern "C" int da_groupnorm_bwd(const void* X, long ldx, const void* dY, long ld
 
 extern "C" int da_colsum_accum(const void* X, long ldx, float* out, float* scratch, int M, int C,
                                hipStream_t stream) {
+  DA_CLEAR_ERR();
   if (M <= 0 || C <= 0 || (C & 7) || (ldx & 7)) return DA_ERR_SHAPE;
   ChanReduceParams p = {};
   p.X = (const bf16*)X; p.ldx = ldx; p.partial = scratch;
@@ -490,6 +493,7 @@ extern "C" int da_colsum_accum(const void* X, long ldx, float* out, float* scrat
 
 extern "C" int da_image_colsum(const void* X, long ldx, void* out, long ldo, float* db, float* scratch, int B, int HW,
                                int C, hipStream_t stream) {
+  DA_CLEAR_ERR();
   if (B <= 0 || HW <= 0 || C <= 0 || (C & 7) || (ldx & 7)) return DA_ERR_SHAPE;
   ChanReduceParams p = {};
   p.X = (const bf16*)X; p.ldx = ldx; p.partial = scratch;
@@ -504,6 +508,7 @@ extern "C" int da_image_colsum(const void* X, long ldx, void* out, long ldo, flo
 
 extern "C" int da_layernorm_fwd(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta,
                                 float* mean_rstd, int M, int C, float eps, hipStream_t stream) {
+  DA_CLEAR_ERR();
   if (M <= 0 || C <= 0 || (C & 7) || C > 8 * 64 * LN_MAXV || (ldx & 7) || (ldy & 7)) return DA_ERR_SHAPE;
   int blocks = (M + 3) / 4;
   if (blocks > 4096) blocks = 4096;
@@ -516,6 +521,7 @@ extern "C" int da_layernorm_fwd(const void* X, long ldx, void* Y, long ldy, cons
 extern "C" int da_layernorm_bwd(const void* X, long ldx, const void* dY, long lddy, const void* Radd, long ldr,
                                 void* dX, long lddx, const float* gamma, const float* mean_rstd, float* dgamma,
                                 float* dbeta, float* scratch, int M, int C, hipStream_t stream) {
+  DA_CLEAR_ERR();
   if (M <= 0 || C <= 0 || (C & 7) || C > 8 * 64 * LN_MAXV || (ldx & 7) || (lddy & 7) || (lddx & 7))
     return DA_ERR_SHAPE;
   if (Radd && (ldr & 7)) return DA_ERR_SHAPE;

@@ -274,6 +274,7 @@ __global__ void transpose_weight_kernel(const bf16* src, bf16* dst, int N, int T
 #define CHK8(x) if ((x) & 7) return DA_ERR_SHAPE
 
 extern "C" int da_geglu_fwd(const void* in, long ldi, void* out, long ldo, int M, int Cout, hipStream_t s) {
+  DA_CLEAR_ERR();
   if (M <= 0 || Cout <= 0) return DA_ERR_SHAPE;
   CHK8(Cout); CHK8(ldi); CHK8(ldo);
   long total = (long)M * (Cout >> 3);
@@ -284,6 +285,7 @@ extern "C" int da_geglu_fwd(const void* in, long ldi, void* out, long ldo, int M
 }
 extern "C" int da_geglu_bwd(const void* in, long ldi, const void* dout, long lddo, void* din, long lddi, int M,
                             int Cout, hipStream_t s) {
+  DA_CLEAR_ERR();
   if (M <= 0 || Cout <= 0) return DA_ERR_SHAPE;
   CHK8(Cout); CHK8(ldi); CHK8(lddo); CHK8(lddi);
   long total = (long)M * (Cout >> 3);
@@ -293,6 +295,7 @@ extern "C" int da_geglu_bwd(const void* in, long ldi, const void* dout, long ldd
   return DA_OK;
 }
 extern "C" int da_silu_fwd(const void* x, long ldx, void* y, long ldy, int M, int C, hipStream_t s) {
+  DA_CLEAR_ERR();
   if (M <= 0 || C <= 0) return DA_ERR_SHAPE;
   CHK8(C); CHK8(ldx); CHK8(ldy);
   long total = (long)M * (C >> 3);
@@ -303,6 +306,7 @@ extern "C" int da_silu_fwd(const void* x, long ldx, void* y, long ldy, int M, in
 }
 extern "C" int da_silu_bwd(const void* x, long ldx, const void* dy, long lddy, void* dx, long lddx, int M, int C,
                            hipStream_t s) {
+  DA_CLEAR_ERR();
   if (M <= 0 || C <= 0) return DA_ERR_SHAPE;
   CHK8(C); CHK8(ldx); CHK8(lddy); CHK8(lddx);
   long total = (long)M * (C >> 3);
@@ -313,6 +317,7 @@ extern "C" int da_silu_bwd(const void* x, long ldx, const void* dy, long lddy, v
 }
 extern "C" int da_add(const void* a, long lda, const void* b, long ldb, void* o, long ldo, int M, int C,
                       hipStream_t s) {
+  DA_CLEAR_ERR();
   if (M <= 0 || C <= 0) return DA_ERR_SHAPE;
   CHK8(C); CHK8(lda); CHK8(ldb); CHK8(ldo);
   long total = (long)M * (C >> 3);
@@ -322,6 +327,7 @@ extern "C" int da_add(const void* a, long lda, const void* b, long ldb, void* o,
   return DA_OK;
 }
 extern "C" int da_copy2d(const void* a, long lda, void* o, long ldo, int M, int C, hipStream_t s) {
+  DA_CLEAR_ERR();
   if (M <= 0 || C <= 0) return DA_ERR_SHAPE;
   CHK8(C); CHK8(lda); CHK8(ldo);
   long total = (long)M * (C >> 3);
@@ -331,6 +337,7 @@ extern "C" int da_copy2d(const void* a, long lda, void* o, long ldo, int M, int 
   return DA_OK;
 }
 extern "C" int da_upsample2x_fwd(const void* x, void* y, int B, int H, int W, int C, hipStream_t s) {
+  DA_CLEAR_ERR();
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DA_ERR_SHAPE;
   CHK8(C);
   long total = (long)B * 4 * H * W * (C >> 3);
@@ -340,6 +347,7 @@ extern "C" int da_upsample2x_fwd(const void* x, void* y, int B, int H, int W, in
   return DA_OK;
 }
 extern "C" int da_upsample2x_bwd(const void* dy, void* dx, int B, int H, int W, int C, hipStream_t s) {
+  DA_CLEAR_ERR();
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DA_ERR_SHAPE;
   CHK8(C);
   long total = (long)B * H * W * (C >> 3);
@@ -349,6 +357,7 @@ extern "C" int da_upsample2x_bwd(const void* dy, void* dx, int B, int H, int W, 
   return DA_OK;
 }
 extern "C" int da_timestep_embed(const long long* t, void* out, int B, int dim, hipStream_t s) {
+  DA_CLEAR_ERR();
   if (B <= 0 || dim <= 0 || (dim & 1)) return DA_ERR_SHAPE;
   hipLaunchKernelGGL(timestep_embed_kernel, dim3(pw_blocks((long)B * dim / 2)), dim3(PW_BLOCK), 0, s, t, (bf16*)out,
                      B, dim);
@@ -358,6 +367,7 @@ extern "C" int da_timestep_embed(const long long* t, void* out, int B, int dim, 
 extern "C" int da_add_noise(const float* x0, const float* eps, const long long* t, const float* sqrt_ac,
                             const float* sqrt_1mac, void* xt, float* target, int B, int HW, int v_pred,
                             hipStream_t s) {
+  DA_CLEAR_ERR();
   if (B <= 0 || HW <= 0) return DA_ERR_SHAPE;
   long total = (long)B * HW;
   hipLaunchKernelGGL(add_noise_kernel, dim3(pw_blocks(total)), dim3(PW_BLOCK), 0, s, x0, eps, t, sqrt_ac, sqrt_1mac,
@@ -367,6 +377,7 @@ extern "C" int da_add_noise(const float* x0, const float* eps, const long long* 
 }
 extern "C" int da_mse_loss(const float* pred, const float* target, void* dpred, float* loss, float* scratch,
                            long total_pix, float grad_coef, float weight, int accumulate, hipStream_t s) {
+  DA_CLEAR_ERR();
   if (total_pix <= 0) return DA_ERR_SHAPE;
   int blocks = pw_blocks(total_pix);
   if (blocks > 1024) blocks = 1024;
@@ -380,6 +391,7 @@ extern "C" int da_mse_loss(const float* pred, const float* target, void* dpred, 
 }
 extern "C" int da_adamw(float* p, const float* g, float* m, float* v, void* shadow, long n, float lr, float beta1,
                         float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s) {
+  DA_CLEAR_ERR();
   if (n <= 0 || step <= 0) return DA_ERR_SHAPE;
   if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) || ((uintptr_t)shadow & 7))
     return DA_ERR_SHAPE;
@@ -391,12 +403,14 @@ extern "C" int da_adamw(float* p, const float* g, float* m, float* v, void* shad
   return DA_OK;
 }
 extern "C" int da_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t s) {
+  DA_CLEAR_ERR();
   if (n <= 0) return DA_ERR_SHAPE;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(pw_blocks(n)), dim3(PW_BLOCK), 0, s, src, (bf16*)dst, n);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
 extern "C" int da_transpose_weight(const void* src, void* dst, int N, int T, int C, hipStream_t s) {
+  DA_CLEAR_ERR();
   if (N <= 0 || T <= 0 || C <= 0) return DA_ERR_SHAPE;
   hipLaunchKernelGGL(transpose_weight_kernel, dim3((C + 31) / 32, (N + 31) / 32, T), dim3(256), 0, s,
                      (const bf16*)src, (bf16*)dst, N, T, C);
