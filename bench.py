@@ -88,7 +88,7 @@ def main():
 
     S = a.latent
     B = a.batch or {32: 256, 64: 64, 96: 16}[S]
-    mb = a.microbatch or {32: 64, 64: 16, 96: 8}[S]
+    mb = a.microbatch or {32: 256, 64: 64, 96: 16}[S]
     name = 'stabilityai/stable-diffusion-2' if S == 96 else 'stabilityai/stable-diffusion-2-base'
     torch.manual_seed(17 + rank)
     model = stable_diffusion_2(model_name=name, pretrained=False, precomputed_latents=True, fsdp=False, seed=17)

@@ -249,33 +249,65 @@ __global__ void gn_bwd_apply_kernel(const bf16* X, long ldx, const bf16* DY, lon
 }
 
 // out1[c] (+)= sum_rows partial[row][c][0] ; out2[c] (+)= sum_rows partial[row][c][1]
-__global__ void chan_sum_finalize_kernel(const float* partial, int nrows, int C, float* out1, float* out2,
-                                         int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 32 channels x 8 row-lanes (float2 loads, 256 B per row segment), LDS tree over the row-lanes
+__global__ __launch_bounds__(256) void chan_sum_finalize_kernel(const float* partial, int nrows, int C, float* out1,
+                                                                float* out2, int accumulate) {
+  __shared__ float sh[8][32][2];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   float a = 0.f, q = 0.f;
-  for (int k = 0; k < nrows; ++k) {
-    const float* pp = partial + ((long)k * C + c) * 2;
-    a += pp[0];
-    q += pp[1];
+  if (c < C) {
+    const float2* pp = reinterpret_cast<const float2*>(partial) + c;
+    int k = ry;
+    for (; k + 24 < nrows; k += 32) {
+      float2 v0 = pp[(long)k * C], v1 = pp[(long)(k + 8) * C], v2 = pp[(long)(k + 16) * C], v3 = pp[(long)(k + 24) * C];
+      a += (v0.x + v1.x) + (v2.x + v3.x);
+      q += (v0.y + v1.y) + (v2.y + v3.y);
+    }
+    for (; k < nrows; k += 8) {
+      float2 v = pp[(long)k * C];
+      a += v.x;
+      q += v.y;
+    }
   }
-  if (out1) out1[c] = accumulate ? out1[c] + a : a;
-  if (out2) out2[c] = accumulate ? out2[c] + q : q;
+  sh[ry][cx][0] = a;
+  sh[ry][cx][1] = q;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      a += sh[j][cx][0];
+      q += sh[j][cx][1];
+    }
+    if (out1) out1[c] = accumulate ? out1[c] + a : a;
+    if (out2) out2[c] = accumulate ? out2[c] + q : q;
+  }
 }
 
 // out[b][c] = sum_chunks partial[b][chunk][c][0] (bf16, strided) ; db[c] += sum_b out[b][c] (fp32)
-__global__ void image_colsum_finalize_kernel(const float* partial, bf16* out, long ldo, float* db, int B, int nchunks,
-                                             int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 32 channels x 8 image-lanes
+__global__ __launch_bounds__(256) void image_colsum_finalize_kernel(const float* partial, bf16* out, long ldo, float* db,
+                                                                    int B, int nchunks, int C) {
+  __shared__ float sh[8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   float tot = 0.f;
-  for (int b = 0; b < B; ++b) {
-    float a = 0.f;
-    for (int k = 0; k < nchunks; ++k) a += partial[(((long)b * nchunks + k) * C + c) * 2];
-    out[(long)b * ldo + c] = f2bf(a);
-    tot += a;
+  if (c < C) {
+    for (int b = ry; b < B; b += 8) {
+      const float* pp = partial + ((long)b * nchunks * C + c) * 2;
+      float a = 0.f;
+      for (int k = 0; k < nchunks; ++k) a += pp[(long)k * C * 2];
+      out[(long)b * ldo + c] = f2bf(a);
+      tot += a;
+    }
   }
-  if (db) db[c] += tot;
+  sh[ry][cx] = tot;
+  __syncthreads();
+  if (ry == 0 && c < C && db) {
+#pragma unroll
+    for (int j = 1; j < 8; ++j) tot += sh[j][cx];
+    db[c] += tot;
+  }
 }
 
 // ---- LayerNorm: one wave per row, row kept in registers (C <= 1536)
@@ -459,7 +491,7 @@ extern "C" int da_groupnorm_bwd(const void* X, long ldx, const void* dY, long ld
                      gamma, coef, C, G, C / G, p.nchunks, HW);
   DA_CHECK_LAUNCH();
   // dgamma[c] += sum_b s2, dbeta[c] += sum_b s1
-  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch,
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, scratch,
                      B * p.nchunks, C, dbeta, dgamma, 1);
   DA_CHECK_LAUNCH();
   const long total_vec = (long)B * HW * (C >> 3);
@@ -485,7 +517,7 @@ extern "C" int da_colsum_accum(const void* X, long ldx, float* out, float* scrat
   p.nchunks = n;
   int rc = launch_chan_reduce(2, p, 1, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, n, C, out,
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, scratch, n, C, out,
                      (float*)nullptr, 1);
   DA_CHECK_LAUNCH();
   return DA_OK;
@@ -500,7 +532,7 @@ extern "C" int da_image_colsum(const void* X, long ldx, void* out, long ldo, flo
   p.HW = HW; p.C = C; p.G = 1; p.cpg = C; p.nchunks = pick_chunks(B, HW);
   int rc = launch_chan_reduce(2, p, B, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(image_colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, (bf16*)out,
+  hipLaunchKernelGGL(image_colsum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, scratch, (bf16*)out,
                      ldo, db, B, p.nchunks, C);
   DA_CHECK_LAUNCH();
   return DA_OK;
@@ -531,7 +563,7 @@ extern "C" int da_layernorm_bwd(const void* X, long ldx, const void* dY, long ld
                      (const bf16*)X, ldx, (const bf16*)dY, lddy, (const bf16*)Radd, ldr, (bf16*)dX, lddx, gamma,
                      mean_rstd, scratch, M, C);
   DA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, blocks, C,
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, scratch, blocks, C,
                      dgamma, dbeta, 1);
   DA_CHECK_LAUNCH();
   return DA_OK;

@@ -129,48 +129,13 @@ class FlatParams:
         self.views.append((key, storage, fn))
 
 
-class UNetOutput(dict):
-    """Supports both ``out['sample']`` (stable_diffusion.py:183) and ``out.sample`` (:367)."""
+def build_layout(cfg: UNetConfig):
+    """Flat-buffer layout (pure host logic): storages in forward order + the diffusers-named views onto them."""
+    class _S:
+        pass
 
-    @property
-    def sample(self):
-        return self['sample']
-
-
-class UNetHIP(nn.Module):
-    def __init__(self, cfg: Optional[UNetConfig] = None, device='cuda', seed: int = 17, init: bool = True):
-        super().__init__()
-        self.cfg = cfg or UNetConfig.sd2_base()
-        self.cfg.validate()
-        self.config = self.cfg  # stable_diffusion.py:329,349 read unet.config.sample_size / in_channels
-        self.device_ = torch.device(device)
-        if self.device_.type != 'cuda':
-            raise RuntimeError('UNetHIP runs on an MI355X only (no CPU fallback); device must be cuda')
-        from .. import _lib
-        _lib.load()  # fail loudly if the HIP library is missing
-        self._build_layout()
-        dev = self.device_
-        fp = self.fp
-        self.master = torch.zeros(fp.total, device=dev, dtype=F32)
-        self.grad = torch.zeros(fp.total, device=dev, dtype=F32)
-        self.exp_avg = torch.zeros(fp.total, device=dev, dtype=F32)
-        self.exp_avg_sq = torch.zeros(fp.total, device=dev, dtype=F32)
-        self.shadow = torch.zeros(fp.total, device=dev, dtype=BF16)
-        self.shadow_t = torch.zeros(max(fp.total_t, 8), device=dev, dtype=BF16)
-        self._bind_views()
-        self._scratch = None
-        self._scratch_key = None
-        self.opt_step = 0
-        self._grad_ready_cb = None  # parallel.BucketedAllReducer.ready during the last microbatch
-        self._tape = None
-        if init:
-            self.reset_parameters(seed)
-
-    # ------------------------------------------------------------------------------------------
-    # layout
-    # ------------------------------------------------------------------------------------------
-    def _build_layout(self):
-        cfg = self.cfg
+    self = _S()
+    if True:  # (indentation kept from the original method body)
         fp = FlatParams()
         boc = cfg.block_out_channels
         temb = cfg.time_embed_dim
@@ -282,8 +247,50 @@ class UNetHIP(nn.Module):
                 conv3(f'up_blocks.{i}.upsamplers.0.conv', rev[i], rev[i])
         vecpair('conv_norm_out', boc[0])
         conv3('conv_out', cfg.out_channels, boc[0], cout_pad=8)
-        self.fp = fp
+    return fp, self.resnet_names, self.tproj_offsets, self.tproj_total
 
+
+
+class UNetOutput(dict):
+    """Supports both ``out['sample']`` (stable_diffusion.py:183) and ``out.sample`` (:367)."""
+
+    @property
+    def sample(self):
+        return self['sample']
+
+
+class UNetHIP(nn.Module):
+    def __init__(self, cfg: Optional[UNetConfig] = None, device='cuda', seed: int = 17, init: bool = True):
+        super().__init__()
+        self.cfg = cfg or UNetConfig.sd2_base()
+        self.cfg.validate()
+        self.config = self.cfg  # stable_diffusion.py:329,349 read unet.config.sample_size / in_channels
+        self.device_ = torch.device(device)
+        if self.device_.type != 'cuda':
+            raise RuntimeError('UNetHIP runs on an MI355X only (no CPU fallback); device must be cuda')
+        from .. import _lib
+        _lib.load()  # fail loudly if the HIP library is missing
+        self.fp, self.resnet_names, self.tproj_offsets, self.tproj_total = build_layout(self.cfg)
+        dev = self.device_
+        fp = self.fp
+        self.master = torch.zeros(fp.total, device=dev, dtype=F32)
+        self.grad = torch.zeros(fp.total, device=dev, dtype=F32)
+        self.exp_avg = torch.zeros(fp.total, device=dev, dtype=F32)
+        self.exp_avg_sq = torch.zeros(fp.total, device=dev, dtype=F32)
+        self.shadow = torch.zeros(fp.total, device=dev, dtype=BF16)
+        self.shadow_t = torch.zeros(max(fp.total_t, 8), device=dev, dtype=BF16)
+        self._bind_views()
+        self._scratch = None
+        self._scratch_key = None
+        self.opt_step = 0
+        self._grad_ready_cb = None  # parallel.BucketedAllReducer.ready during the last microbatch
+        self._tape = None
+        if init:
+            self.reset_parameters(seed)
+
+    # ------------------------------------------------------------------------------------------
+    # layout
+    # ------------------------------------------------------------------------------------------
     def _bind_views(self):
         fp = self.fp
         self._mats: Dict[str, Mat] = {}
