@@ -14,6 +14,8 @@
 // ds_read_b128 fragment reads of the 16x16x32 operand map are bank-conflict free.
 // Epilogue: accumulators -> per-wave fp32 LDS tile -> full 16-B row segments with fused
 // bias / per-image row bias (timestep FiLM) / residual add -> bf16 (or fp32) global stores.
+#include <string.h>
+
 #include "common.hpp"
 #include "diffusion_amd.h"
 
@@ -236,6 +238,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
 
 }  // namespace
 
+// large-tile LDS-DMA variant (gemm_nt_v2.hip)
+int da_gemm_nt_v2_dispatch(int variant, const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
+                           const void* rowbias, long ldrb, const void* R, long ldr, int M, int N, int K, int Cin,
+                           int Hin, int Win, int Hout, int Wout, int ksize, int mode, int out_fp32, float alpha,
+                           hipStream_t stream);
+
+static int g_nt_variant = 0;  // 0 auto, 1 force v1 (128x128), 4 / 5 force v2 with BN 128 / 160 (when eligible)
+
+extern "C" int da_set_option(const char* key, int value) {
+  if (key && !strcmp(key, "gemm_nt_variant")) {
+    g_nt_variant = value;
+    return DA_OK;
+  }
+  return DA_ERR_SHAPE;
+}
+
 extern "C" int da_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
                           const void* rowbias, long ldrb, const void* R, long ldr, int M, int N, int K, int Cin,
                           int Hin, int Win, int Hout, int Wout, int ksize, int mode, int out_fp32, float alpha,
@@ -249,6 +267,22 @@ extern "C" int da_gemm_nt(const void* A, long lda, const void* W, void* C, long 
   if (Hout <= 0 || Wout <= 0 || (M % (Hout * Wout))) return DA_ERR_SHAPE;
   if (R && (ldr & 7)) return DA_ERR_SHAPE;
   if (rowbias && (ldrb & 7)) return DA_ERR_SHAPE;
+  {
+    const bool eligible = (Cin % 64 == 0);
+    int variant = 1;
+    if (eligible) {
+      if (g_nt_variant == 4 || g_nt_variant == 5) {
+        variant = g_nt_variant;
+      } else if (g_nt_variant == 0) {
+        const int nt = (N % 160 == 0) ? 5 : 4;
+        const long tiles2 = (long)((M + 255) / 256) * ((N + 32 * nt - 1) / (32 * nt));
+        if (tiles2 >= 200) variant = nt;  // one 512-thread workgroup per CU: need most of the 256 CUs busy
+      }
+    }
+    if (variant != 1)
+      return da_gemm_nt_v2_dispatch(variant, A, lda, W, C, ldc, bias, rowbias, ldrb, R, ldr, M, N, K, Cin, Hin, Win,
+                                    Hout, Wout, ksize, mode, out_fp32, alpha, stream);
+  }
   GemmNTParams p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = C; p.bias = bias;
   p.rowbias = (const bf16*)rowbias; p.R = (const bf16*)R;

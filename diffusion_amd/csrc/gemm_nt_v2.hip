@@ -1,0 +1,287 @@
+// gemm_nt v2: large-tile LDS-DMA variant of the implicit-GEMM "NT" kernel (same contract as gemm_nt.hip).
+//
+// Why: the 128x128x64 tile of v1 moves 32 KiB from L2 per 2.1 MFLOP (64 FLOP/B); at the bf16 MFMA peak that is
+// ~39 TB/s of L2->LDS traffic, more than the chip has, and v1 measures ~0.5 PFLOP/s on every large shape.
+// v2 uses a 256 x (128|160) x 64 tile (85 / 98 FLOP/B), 8 waves (4 along M x 2 along N, each 64 x (64|80) from
+// 4 x (4|5) v_mfma_f32_16x16x32_bf16 tiles), one workgroup per CU, and fills LDS with global_load_lds_dwordx4
+// (no staging registers, no ds_write pass).  BN = 160 makes every channel count of the SD-2 U-Net (multiples of
+// 320) tile exactly instead of wasting 17 % on N = 320.
+// LDS-DMA writes lane-linearly (1 KiB = 8 rows x 128 B per wave instruction), so the XOR swizzle that keeps the
+// ds_read_b128 fragment reads conflict-free is applied on the per-lane SOURCE address; out-of-image taps and
+// out-of-range rows read a 128-B zero page instead of being predicated.
+// Two LDS stages; the loads of K-step t+1 are issued before the MFMAs of step t and retired by the
+// vmcnt(0)+barrier that ends the step.  Requires Cin % 64 == 0 (one tap per K-step).
+#include "common.hpp"
+#include "diffusion_amd.h"
+
+namespace {
+
+struct GemmNT2Params {
+  const bf16* A;
+  const bf16* W;
+  void* C;
+  const float* bias;
+  const bf16* rowbias;
+  const bf16* R;
+  long lda, ldc, ldrb, ldr;
+  int M, N, K, Cin;
+  int Hin, Win, Hout, Wout;
+  int ksize, mode;
+  int out_fp32;
+  float alpha;
+  int tiles_m, tiles_n;
+};
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+constexpr int V2_BM = 256, V2_BK = 64;
+
+DEVINL int swz2(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+DEVINL void glds16(const void* gsrc, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int NT>
+__global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
+  constexpr int BN = 32 * NT;
+  constexpr int A_BYTES = V2_BM * V2_BK * 2;  // 32 KiB
+  constexpr int B_BYTES = BN * V2_BK * 2;     // 16 / 20 KiB
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int BGROUPS = BN / 8;             // 1-KiB row groups of the B tile
+  constexpr int EPI_LD = 16 * NT + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nblk = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+  const int m0 = tm * V2_BM, n0 = tn * BN;
+  const int HWo = p.Hout * p.Wout;
+  const int pad = (p.ksize == 3) ? 1 : 0;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // ---- per-lane DMA sources.  A: this wave fills row groups wave*4 .. wave*4+3 (8 rows each).
+  const int lrow = lane >> 3;
+  int pixbase[4], oh[4], ow[4], achunk[4];
+  bool mval[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = wave * 32 + j * 8 + lrow;
+    const int m = m0 + row;
+    mval[j] = m < p.M;
+    const int mm = mval[j] ? m : 0;
+    const int b = mm / HWo;
+    const int rem = mm - b * HWo;
+    oh[j] = rem / p.Wout;
+    ow[j] = rem - oh[j] * p.Wout;
+    pixbase[j] = b * p.Hin * p.Win;
+    achunk[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  // B: row groups wave, wave+8, wave+16 (< BGROUPS)
+  const bf16* wsrc[3];
+  bool wval[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int g = wave + 8 * j;
+    const int row = g * 8 + lrow;
+    const int n = n0 + row;
+    wval[j] = (g < BGROUPS) && (n < p.N);
+    wsrc[j] = p.W + (long)(wval[j] ? n : 0) * p.K + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+
+  int tap = 0, c0 = 0, k0 = 0;
+  auto issue = [&](int stage) {
+    char* Ab = smem + stage * STAGE;
+    char* Bb = Ab + A_BYTES;
+    int r = 0, s = 0;
+    if (p.ksize == 3) {
+      r = tap / 3;
+      s = tap - 3 * r;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int ih, iw;
+      bool ok = mval[j];
+      if (p.mode == 0) {
+        ih = oh[j] + r - pad;
+        iw = ow[j] + s - pad;
+      } else if (p.mode == 1) {
+        ih = 2 * oh[j] + r - pad;
+        iw = 2 * ow[j] + s - pad;
+      } else if (p.mode == 2) {
+        const int th = oh[j] + r - 1, tw = ow[j] + s - 1;
+        ok = ok && !((th | tw) & 1);
+        ih = th >> 1;
+        iw = tw >> 1;
+      } else {
+        const int th = oh[j] + r - 1, tw = ow[j] + s - 1;
+        ok = ok && th >= 0 && tw >= 0 && th < p.Hout && tw < p.Wout;
+        ih = th >> 1;
+        iw = tw >> 1;
+      }
+      ok = ok && ih >= 0 && iw >= 0 && ih < p.Hin && iw < p.Win;
+      const void* src = ok ? (const void*)(p.A + (long)(pixbase[j] + ih * p.Win + iw) * p.lda + c0 + achunk[j])
+                           : (const void*)zero;
+      glds16(src, Ab + (wave * 4 + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int g = wave + 8 * j;
+      if (g < BGROUPS) {
+        const void* src = wval[j] ? (const void*)(wsrc[j] + k0) : (const void*)zero;
+        glds16(src, Bb + g * 1024);
+      }
+    }
+    k0 += V2_BK;
+    c0 += V2_BK;
+    if (c0 >= p.Cin) {
+      c0 = 0;
+      ++tap;
+    }
+  };
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int stage) {
+    const char* Ab = smem + stage * STAGE;
+    const char* Bb = Ab + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[4], b[NT];
+      const int chunk = s * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2(wm * 64 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(Bb + swz2(wn * (16 * NT) + j * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = p.K / V2_BK;
+  issue(0);
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) issue((t + 1) & 1);
+    compute(t & 1);
+    __syncthreads();  // vmcnt(0): step t+1 has landed; barrier: everyone is done reading stage t
+  }
+
+  // ---- epilogue: one 16-row MFMA tile row at a time through a per-wave fp32 LDS strip
+  float* ew = reinterpret_cast<float*>(smem) + wave * (16 * EPI_LD);
+  constexpr int TASKS = 16 * 2 * NT;  // (row, 8-column chunk) pairs per strip
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ew[((lane >> 4) * 4 + e) * EPI_LD + j * 16 + (lane & 15)] = acc[i][j][e];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pss = 0; pss < (TASKS + 63) / 64; ++pss) {
+      const int task = lane + 64 * pss;
+      if (task < TASKS) {
+        const int row = task / (2 * NT);
+        const int col8 = (task - row * (2 * NT)) * 8;
+        const int m = m0 + wm * 64 + i * 16 + row;
+        const int n = n0 + wn * (16 * NT) + col8;
+        if (m < p.M && n < p.N) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8]);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8 + 4]);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          if (p.bias) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = v[e] * p.alpha + b0[e];
+              v[e + 4] = v[e + 4] * p.alpha + b1[e];
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+          }
+          if (p.rowbias) {
+            const int b = m / HWo;
+            const bf16x8 rbv = ld8(p.rowbias + (long)b * p.ldrb + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf2f(rbv[e]);
+          }
+          if (p.R) {
+            const bf16x8 rv = ld8(p.R + (long)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
+          }
+          if (p.out_fp32) {
+            float* cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          } else {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+            st8(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, o);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int NT>
+int launch_v2(const GemmNT2Params& p0, hipStream_t stream) {
+  GemmNT2Params p = p0;
+  constexpr int BN = 32 * NT;
+  constexpr int SMEM = 2 * (V2_BM * V2_BK * 2 + BN * V2_BK * 2);
+  p.tiles_m = (p.M + V2_BM - 1) / V2_BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
+        hipSuccess)
+      return DA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_nt2_kernel<NT>, dim3(p.tiles_m * p.tiles_n), dim3(512), SMEM, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+}  // namespace
+
+// Called by da_gemm_nt (gemm_nt.hip) after argument validation.  variant: 4 -> BN 128, 5 -> BN 160.
+int da_gemm_nt_v2_dispatch(int variant, const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
+                           const void* rowbias, long ldrb, const void* R, long ldr, int M, int N, int K, int Cin,
+                           int Hin, int Win, int Hout, int Wout, int ksize, int mode, int out_fp32, float alpha,
+                           hipStream_t stream) {
+  GemmNT2Params p;
+  p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = C; p.bias = bias;
+  p.rowbias = (const bf16*)rowbias; p.R = (const bf16*)R;
+  p.lda = lda; p.ldc = ldc; p.ldrb = ldrb; p.ldr = ldr;
+  p.M = M; p.N = N; p.K = K; p.Cin = Cin;
+  p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
+  p.ksize = ksize; p.mode = mode; p.out_fp32 = out_fp32; p.alpha = alpha;
+  p.tiles_m = p.tiles_n = 0;
+  return variant == 5 ? launch_v2<5>(p, stream) : launch_v2<4>(p, stream);
+}

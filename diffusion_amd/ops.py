@@ -67,6 +67,10 @@ def _f32buf(x: torch.Tensor, min_numel: int, name='buf') -> int:
     return x.data_ptr()
 
 
+def set_option(key: str, value: int):
+    _lib.call('da_set_option', key.encode(), int(value))
+
+
 class Geom:
     """Geometry of an implicit-GEMM call.  Linear layers: Geom.linear()."""
     __slots__ = ('B', 'Hin', 'Win', 'Hout', 'Wout', 'ksize', 'mode')

@@ -40,6 +40,10 @@ int da_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const 
                long ldrb, const void* R, long ldr, int M, int N, int K, int Cin, int Hin, int Win, int Hout, int Wout,
                int ksize, int mode, int out_fp32, float alpha, da_stream_t stream);
 
+/* tuning / test hook: "gemm_nt_variant" = 0 auto, 1 force the 128x128 kernel, 4 / 5 force the 256x128 / 256x160
+ * LDS-DMA kernel where eligible (Cin % 64 == 0).  Returns DA_ERR_SHAPE for unknown keys. */
+int da_set_option(const char* key, int value);
+
 /* dW[N][ksize*ksize*Cin] += sum_m dY[m][n] * gather(X)[m][k]   (fp32, atomically accumulated).
  * Replaces the cuDNN/cuBLAS wgrad kernels autograd runs for the same layers (loss.backward() driven by
  * Composer).  modes 0, 1, 3 as above. */

@@ -133,6 +133,61 @@ def test_conv_upsample_fused(ops, dev):
     check(from_nhwc(out, B, 2 * H, 2 * Wd), ref, what='up conv')
 
 
+@pytest.mark.parametrize('variant', [4, 5])
+def test_gemm_nt_v2_variants(ops, dev, variant):
+    """The 256x(128|160) LDS-DMA kernel forced on: linear + every conv mode, ragged M / N tails, fused epilogue."""
+    ops.set_option('gemm_nt_variant', variant)
+    try:
+        M, N, K = 1000, 328, 320
+        A = rnd(M, K, dev=dev, seed=1).to(BF); W = rnd(N, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
+        bias = rnd(N, dev=dev, seed=3); R = rnd(M, N, dev=dev, seed=4).to(BF)
+        out = torch.empty(M, N, device=dev, dtype=BF)
+        ops.gemm_nt(A, W, out, ops.Geom.linear(M), bias=bias, residual=R, alpha=0.5)
+        check(out, 0.5 * (A.float() @ W.float().t()) + bias + R.float(), what='v2 linear')
+        out32 = torch.empty(M, N, device=dev, dtype=torch.float32)
+        ops.gemm_nt(A, W, out32, ops.Geom.linear(M))
+        check(out32, A.float() @ W.float().t(), tol=1e-5, what='v2 linear fp32')
+        B, H, Wd, C, Co = 3, 12, 12, 64, 200
+        x = rnd(B, C, H, Wd, dev=dev, seed=1).to(BF)
+        w = rnd(Co, C, 3, 3, dev=dev, seed=2, scale=(9 * C)**-0.5).to(BF)
+        rb = rnd(B, Co, dev=dev, seed=4).to(BF)
+        o = torch.empty(B * H * Wd, Co, device=dev, dtype=BF)
+        ops.gemm_nt(nhwc(x), w_ohwi(w), o, ops.Geom.conv(B, H, Wd), bias=bias[:Co].contiguous(), rowbias=rb)
+        ref = F.conv2d(x.float(), w.float(), bias[:Co], padding=1) + rb.float()[:, :, None, None]
+        check(from_nhwc(o, B, H, Wd), ref, what='v2 conv3x3')
+        o2 = torch.empty(B * (H // 2) * (Wd // 2), Co, device=dev, dtype=BF)
+        ops.gemm_nt(nhwc(x), w_ohwi(w), o2, ops.Geom.down(B, H, Wd))
+        xr = x.float().requires_grad_(True)
+        r2 = F.conv2d(xr, w.float(), stride=2, padding=1)
+        check(from_nhwc(o2, B, H // 2, Wd // 2), r2, what='v2 conv s2')
+        dy = rnd(*r2.shape, dev=dev, seed=3).to(BF)
+        r2.backward(dy.float())
+        Cop = 256  # dgrad needs Cout % 64 == 0 on the K side: pad the test's Cout
+        w3 = rnd(Cop, C, 3, 3, dev=dev, seed=5, scale=(9 * C)**-0.5).to(BF)
+        xr3 = x.float().requires_grad_(True)
+        r3 = F.conv2d(xr3, w3.float(), stride=2, padding=1)
+        dy3 = rnd(*r3.shape, dev=dev, seed=6).to(BF)
+        r3.backward(dy3.float())
+        wt = torch.empty(C, 9 * Cop, device=dev, dtype=BF)
+        ops.transpose_weight(w_ohwi(w3), wt, Cop, 9, C)
+        dx = torch.empty(B * H * Wd, C, device=dev, dtype=BF)
+        ops.gemm_nt(nhwc(dy3), wt, dx, ops.Geom.down_dgrad(B, H, Wd))
+        check(from_nhwc(dx, B, H, Wd), xr3.grad, what='v2 dgrad s2')
+        o4 = torch.empty(B * 4 * H * Wd, Co, device=dev, dtype=BF)
+        ops.gemm_nt(nhwc(x), w_ohwi(w), o4, ops.Geom.up(B, H, Wd))
+        check(from_nhwc(o4, B, 2 * H, 2 * Wd),
+              F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode='nearest'), w.float(), padding=1), what='v2 up')
+        # strided views in and out
+        buf = rnd(600, 3 * 64, dev=dev, seed=5).to(BF)
+        Wl = rnd(160, 64, dev=dev, seed=6, scale=0.1).to(BF)
+        ob = torch.zeros(600, 400, device=dev, dtype=BF)
+        ops.gemm_nt(buf[:, 64:128], Wl, ob[:, 80:240], ops.Geom.linear(600))
+        check(ob[:, 80:240], buf[:, 64:128].float() @ Wl.float().t(), what='v2 strided')
+        assert (ob[:, :80] == 0).all() and (ob[:, 240:] == 0).all()
+    finally:
+        ops.set_option('gemm_nt_variant', 0)
+
+
 # ------------------------------------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize('mode', ['s1', 's2', 'up', '1x1'])
 @pytest.mark.parametrize('B,H,Wd,C,Co', [(2, 12, 12, 64, 72), (3, 8, 8, 8, 320), (2, 16, 16, 320, 8)])
