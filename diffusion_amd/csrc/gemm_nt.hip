@@ -271,12 +271,14 @@ extern "C" int da_gemm_nt(const void* A, long lda, const void* W, void* C, long 
     const bool eligible = (Cin % 64 == 0);
     int variant = 1;
     if (eligible) {
-      if (g_nt_variant == 4 || g_nt_variant == 5) {
+      if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10) {
         variant = g_nt_variant;
       } else if (g_nt_variant == 0) {
-        const int nt = (N % 160 == 0) ? 5 : 4;
-        const long tiles2 = (long)((M + 255) / 256) * ((N + 32 * nt - 1) / (32 * nt));
-        if (tiles2 >= 200) variant = nt;  // one 512-thread workgroup per CU: need most of the 256 CUs busy
+        // one 512-thread workgroup per CU: pick the largest tile that still keeps most of the 256 CUs busy
+        const long tm = (M + 255) / 256;
+        if (N % 320 == 0 && tm * (N / 320) >= 160) variant = 10;
+        else if (N % 160 == 0 && tm * (N / 160) >= 200) variant = 5;
+        else if (N % 160 != 0 && tm * ((N + 127) / 128) >= 200) variant = 4;
       }
     }
     if (variant != 1)

@@ -43,9 +43,12 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int NT>
+// MT x NT = 16x16 MFMA tiles per wave; WM x WN = wave grid (8 waves); BM = 16*MT*WM = 256, BN = 16*NT*WN
+template <int MT, int NT, int WM, int WN>
 __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
-  constexpr int BN = 32 * NT;
+  static_assert(WM * WN == 8 && 16 * MT * WM == V2_BM, "wave grid");
+  constexpr int BN = 16 * NT * WN;
+  constexpr int BJ = (BN / 8 + 7) / 8;  // B row groups per wave
   constexpr int A_BYTES = V2_BM * V2_BK * 2;  // 32 KiB
   constexpr int B_BYTES = BN * V2_BK * 2;     // 16 / 20 KiB
   constexpr int STAGE = A_BYTES + B_BYTES;
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   const int nblk = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
@@ -87,11 +90,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
     pixbase[j] = b * p.Hin * p.Win;
     achunk[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
   }
-  // B: row groups wave, wave+8, wave+16 (< BGROUPS)
-  const bf16* wsrc[3];
-  bool wval[3];
+  // B: row groups wave, wave+8, ... (< BGROUPS)
+  const bf16* wsrc[BJ];
+  bool wval[BJ];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < BJ; ++j) {
     const int g = wave + 8 * j;
     const int row = g * 8 + lrow;
     const int n = n0 + row;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
       glds16(src, Ab + (wave * 4 + j) * 1024);
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < BJ; ++j) {
       const int g = wave + 8 * j;
       if (g < BGROUPS) {
         const void* src = wval[j] ? (const void*)(wsrc[j] + k0) : (const void*)zero;
@@ -150,9 +153,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
     }
   };
 
-  f32x4 acc[4][NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -161,15 +164,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
     const char* Bb = Ab + A_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 a[4], b[NT];
+      bf16x8 a[MT], b[NT];
       const int chunk = s * 4 + (lane >> 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2(wm * 64 + i * 16 + (lane & 15), chunk));
+      for (int i = 0; i < MT; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2(wm * (16 * MT) + i * 16 + (lane & 15), chunk));
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         b[j] = *reinterpret_cast<const bf16x8*>(Bb + swz2(wn * (16 * NT) + j * 16 + (lane & 15), chunk));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
   float* ew = reinterpret_cast<float*>(smem) + wave * (16 * EPI_LD);
   constexpr int TASKS = 16 * 2 * NT;  // (row, 8-column chunk) pairs per strip
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
       if (task < TASKS) {
         const int row = task / (2 * NT);
         const int col8 = (task - row * (2 * NT)) * 8;
-        const int m = m0 + wm * 64 + i * 16 + row;
+        const int m = m0 + wm * (16 * MT) + i * 16 + row;
         const int n = n0 + wn * (16 * NT) + col8;
         if (m < p.M && n < p.N) {
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8]);
@@ -249,28 +253,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
   }
 }
 
-template <int NT>
+template <int MT, int NT, int WM, int WN>
 int launch_v2(const GemmNT2Params& p0, hipStream_t stream) {
   GemmNT2Params p = p0;
-  constexpr int BN = 32 * NT;
+  constexpr int BN = 16 * NT * WN;
   constexpr int SMEM = 2 * (V2_BM * V2_BK * 2 + BN * V2_BK * 2);
   p.tiles_m = (p.M + V2_BM - 1) / V2_BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
+    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<MT, NT, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
         hipSuccess)
       return DA_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_nt2_kernel<NT>, dim3(p.tiles_m * p.tiles_n), dim3(512), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(512), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
 
 }  // namespace
 
-// Called by da_gemm_nt (gemm_nt.hip) after argument validation.  variant: 4 -> BN 128, 5 -> BN 160.
+// Called by da_gemm_nt (gemm_nt.hip) after argument validation.  variant: 4 -> BN 128, 5 -> BN 160, 10 -> BN 320.
 int da_gemm_nt_v2_dispatch(int variant, const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
                            const void* rowbias, long ldrb, const void* R, long ldr, int M, int N, int K, int Cin,
                            int Hin, int Win, int Hout, int Wout, int ksize, int mode, int out_fp32, float alpha,
@@ -283,5 +287,6 @@ int da_gemm_nt_v2_dispatch(int variant, const void* A, long lda, const void* W, 
   p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
   p.ksize = ksize; p.mode = mode; p.out_fp32 = out_fp32; p.alpha = alpha;
   p.tiles_m = p.tiles_n = 0;
-  return variant == 5 ? launch_v2<5>(p, stream) : launch_v2<4>(p, stream);
+  if (variant == 10) return launch_v2<8, 5, 2, 4>(p, stream);
+  return variant == 5 ? launch_v2<4, 5, 4, 2>(p, stream) : launch_v2<4, 4, 4, 2>(p, stream);
 }

@@ -39,7 +39,7 @@ def main(mb=64):
         g = Geom.conv(B, H, H, k)
         fl = 2.0 * M * Cout * k * k * Cin
         res = []
-        for var in (1, 4, 5):
+        for var in (1, 5, 10):
             ops.set_option('gemm_nt_variant', var)
             res.append(timeit(lambda: ops.gemm_nt(x, w, y, g)))
         ops.set_option('gemm_nt_variant', 0)
@@ -48,7 +48,7 @@ def main(mb=64):
         dy = torch.randn(M, Cout, device=dev).to(BF)
         t2 = timeit(lambda: ops.gemm_tn_wgrad(dy, x, dW, g))
         tiles = -(-M // 128) * -(-Cout // 128)
-        print(f'{name:28s} M={M:6d} N={Cout:5d} K={k*k*Cin:6d} tiles={tiles:5d} | nt v1 {fl/res[0]/1e9:6.1f} v2/128 {fl/res[1]/1e9:6.1f} v2/160 {fl/res[2]/1e9:6.1f} auto {fl/t/1e9:6.1f} TF/s | tn {t2*1e3:8.1f} us {fl/t2/1e9:7.1f} TF/s')
+        print(f'{name:28s} M={M:6d} N={Cout:5d} K={k*k*Cin:6d} tiles={tiles:5d} | nt v1 {fl/res[0]/1e9:6.1f} v2/160 {fl/res[1]/1e9:6.1f} v2/320 {fl/res[2]/1e9:6.1f} auto {fl/t/1e9:6.1f} TF/s | tn {t2*1e3:8.1f} us {fl/t2/1e9:7.1f} TF/s')
 
 
 if __name__ == '__main__':
