@@ -244,11 +244,16 @@ int da_gemm_nt_v2_dispatch(int variant, const void* A, long lda, const void* W, 
                            int Hin, int Win, int Hout, int Wout, int ksize, int mode, int out_fp32, float alpha,
                            hipStream_t stream);
 
+extern int g_tn_variant;  // gemm_tn.hip
 static int g_nt_variant = 0;  // 0 auto, 1 force v1 (128x128), 4 / 5 force v2 with BN 128 / 160 (when eligible)
 
 extern "C" int da_set_option(const char* key, int value) {
   if (key && !strcmp(key, "gemm_nt_variant")) {
     g_nt_variant = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "gemm_tn_variant")) {
+    g_tn_variant = value;
     return DA_OK;
   }
   return DA_ERR_SHAPE;

@@ -71,6 +71,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
   const int m0 = tm * V2_BM, n0 = tn * BN;
   const int HWo = p.Hout * p.Wout;
   const int pad = (p.ksize == 3) ? 1 : 0;
+  const int gmul = (p.mode == 1) ? 2 : 1, gshift = (p.mode >= 2) ? 1 : 0, pmask = (p.mode == 2) ? 1 : 0;
+  const int hlim = (p.mode >= 2) ? 2 * p.Hin : p.Hin, wlim = (p.mode >= 2) ? 2 * p.Win : p.Win;
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
   // ---- per-lane DMA sources.  A: this wave fills row groups wave*4 .. wave*4+3 (8 rows each).
@@ -113,26 +115,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int ih, iw;
-      bool ok = mval[j];
-      if (p.mode == 0) {
-        ih = oh[j] + r - pad;
-        iw = ow[j] + s - pad;
-      } else if (p.mode == 1) {
-        ih = 2 * oh[j] + r - pad;
-        iw = 2 * ow[j] + s - pad;
-      } else if (p.mode == 2) {
-        const int th = oh[j] + r - 1, tw = ow[j] + s - 1;
-        ok = ok && !((th | tw) & 1);
-        ih = th >> 1;
-        iw = tw >> 1;
-      } else {
-        const int th = oh[j] + r - 1, tw = ow[j] + s - 1;
-        ok = ok && th >= 0 && tw >= 0 && th < p.Hout && tw < p.Wout;
-        ih = th >> 1;
-        iw = tw >> 1;
-      }
-      ok = ok && ih >= 0 && iw >= 0 && ih < p.Hin && iw < p.Win;
+      // branch-free tap geometry (modes: 0 stride 1, 1 stride 2, 2 dgrad of stride 2, 3 fused nearest-2x upsample)
+      const int th = oh[j] * gmul + r - pad, tw = ow[j] * gmul + s - pad;
+      const bool ok = mval[j] && (unsigned)th < (unsigned)hlim && (unsigned)tw < (unsigned)wlim && !((th | tw) & pmask);
+      const int ih = th >> gshift, iw = tw >> gshift;
       const void* src = ok ? (const void*)(p.A + (long)(pixbase[j] + ih * p.Win + iw) * p.lda + c0 + achunk[j])
                            : (const void*)zero;
       glds16(src, Ab + (wave * 4 + j) * 1024);

@@ -1,0 +1,267 @@
+// gemm_tn v2: large-tile LDS-DMA weight-gradient kernel (same contract as gemm_tn.hip).
+//     dW[n][tap*Cin + c]  +=  sum_m  dY[m][n] * X[pixel(m) + tap][c]
+// Tile: 320 (n) x 256 (k' = tap*Cin+c) fp32 accumulators per 512-thread workgroup (8 waves as 4 x 2, each
+// 80 x 128 = 5 x 8 v_mfma_f32_16x16x32_bf16 tiles), 64 pixels per stage, 2 LDS stages, one workgroup per CU
+// (142 FLOP per byte moved into LDS, as gemm_nt v2's 256x320 tile).  n = 320 tiles every channel count of the
+// SD-2 U-Net exactly.
+// Both operands are staged exactly as they lie in HBM ([pixel][channel] rows) by global_load_lds_dwordx4 and
+// reach the MFMA k-major through ds_read_b64_tr_b16.  Conflict-free transposed reads need the 8 rows a 32-lane
+// half touches to sit in different bank octets; LDS-DMA cannot pad rows, so the 16-B chunk index is XOR-ed
+// on the SOURCE side:  X rows (512 B): chunk ^= 2*(row&7);  dY rows (640 B = 2.5 bank rows): chunk ^= 2*((row>>1)&3)
+// (the odd half bank-row offset of odd rows supplies the third bit).  Out-of-range rows / columns / padding
+// taps read a zero page.  Pixel range is split over workgroups; partials go to the fp32 gradient buffer with
+// global_atomic_add_f32.
+#include "common.hpp"
+#include "diffusion_amd.h"
+
+namespace {
+
+struct GemmTN2Params {
+  const bf16* dY;
+  const bf16* X;
+  float* dW;
+  long lddy, ldx;
+  int M, N, Kt, Cin;
+  int Hin, Win, Hout, Wout, ksize, mode;
+  FastDiv div_hw, div_w, div_cin;
+  int tiles_n, tiles_k, splits, m_per_split;
+};
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page_tn[256];
+
+constexpr int T2_MS = 64;                 // pixels per stage
+constexpr int T2_BN = 320;                // output tile rows (n)
+constexpr int T2_SA = T2_BN * 2;          // 640 B per dY row
+constexpr int T2_A_BYTES = T2_MS * T2_SA;  // 40 KiB
+constexpr int T2_AJ = T2_A_BYTES / 1024 / 8;  // 5 DMA instructions per wave per stage
+
+// source-side XOR of the 16-B chunk index: rows that are a whole number of 256-B bank rows need 3 bits from the
+// row index; rows of an odd number of 128-B halves (640 B, 384 B) get one bit for free from the row parity
+DEVINL int swA(int row) { return 2 * ((row >> 1) & 3); }
+template <int BK>
+DEVINL int swB(int row) { return (BK * 2) % 256 == 0 ? 2 * (row & 7) : 2 * ((row >> 1) & 3); }
+
+DEVINL void glds16_tn(const void* gsrc, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int T2_BK>  // output tile columns (k'): 256 or 192
+__global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
+  constexpr int T2_SB = T2_BK * 2;
+  constexpr int T2_B_BYTES = T2_MS * T2_SB;
+  constexpr int T2_STAGE = T2_A_BYTES + T2_B_BYTES;
+  constexpr int T2_BJ = T2_B_BYTES / 1024 / 8;
+  constexpr int C16B = T2_SB / 16;  // 16-B chunks per X row
+  constexpr int JT = T2_BK / 32;    // 16-column MFMA tiles per wave along k'
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wave >> 1, wb = wave & 1;  // 4 waves along n (80 each) x 2 along k' (128 each)
+
+  int bid = blockIdx.x;
+  const int split = bid % p.splits;
+  bid /= p.splits;
+  const int tk = bid % p.tiles_k;
+  const int tn = bid / p.tiles_k;
+  const int n0 = tn * T2_BN, k0 = tk * T2_BK;
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int nsteps = (m_end - m_begin + T2_MS - 1) / T2_MS;
+  if (nsteps <= 0) return;
+  const int HWo = p.Hout * p.Wout;
+  const int pad = (p.ksize == 3) ? 1 : 0;
+  const int gmul = (p.mode == 1) ? 2 : 1, gshift = (p.mode == 3) ? 1 : 0;
+  const int hlim = (p.mode == 3) ? p.Hout : p.Hin, wlim = (p.mode == 3) ? p.Wout : p.Win;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_tn);
+
+  // ---- DMA source descriptors (fixed per lane and instruction slot for the whole kernel)
+  // dY image: chunk ci = (wave*AJ + j)*64 + lane ; row = ci / 40 ; physical chunk pc = ci % 40 ; logical lc = pc ^ swA(row)
+  int a_row[T2_AJ];
+  int a_off[T2_AJ];
+  bool a_ok[T2_AJ];
+#pragma unroll
+  for (int j = 0; j < T2_AJ; ++j) {
+    const int ci = (wave * T2_AJ + j) * 64 + lane;
+    const int row = ci / 40, pc = ci - row * 40;
+    const int lc = pc ^ swA(row);
+    const int n = n0 + lc * 8;
+    a_row[j] = row;
+    a_ok[j] = n < p.N;
+    a_off[j] = row * (int)p.lddy + n;
+  }
+  // X image: row = ci >> 5 ; pc = ci & 31 ; lc = pc ^ swB(row) ; k' = k0 + lc*8 -> (tap, c)
+  int b_row[T2_BJ], b_dr[T2_BJ], b_ds[T2_BJ], b_c[T2_BJ];
+  bool b_ok[T2_BJ];
+#pragma unroll
+  for (int j = 0; j < T2_BJ; ++j) {
+    const int ci = (wave * T2_BJ + j) * 64 + lane;
+    const int row = ci / C16B, pc = ci - row * C16B;
+    const int lc = pc ^ swB<T2_BK>(row);
+    const int kk = k0 + lc * 8;
+    b_row[j] = row;
+    b_ok[j] = kk < p.Kt;
+    const unsigned tap = b_ok[j] ? fdiv((unsigned)kk, p.div_cin) : 0u;
+    b_c[j] = b_ok[j] ? kk - (int)tap * p.Cin : 0;
+    int r = 0, s = 0;
+    if (p.ksize == 3) {
+      r = (int)tap / 3;
+      s = (int)tap - 3 * r;
+    }
+    b_dr[j] = r;
+    b_ds[j] = s;
+  }
+
+  int mcur = m_begin;
+  auto issue = [&](int stage) {
+    char* Ab = smem + stage * T2_STAGE;
+    char* Bb = Ab + T2_A_BYTES;
+#pragma unroll
+    for (int j = 0; j < T2_AJ; ++j) {
+      const int m = mcur + a_row[j];
+      const void* src = (a_ok[j] && m < m_end) ? (const void*)(p.dY + (long)mcur * p.lddy + a_off[j]) : (const void*)zero;
+      glds16_tn(src, Ab + (wave * T2_AJ + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < T2_BJ; ++j) {
+      const int m = mcur + b_row[j];
+      bool ok = b_ok[j] && m < m_end;
+      const unsigned mm = ok ? (unsigned)m : 0u;
+      const unsigned b = fdiv(mm, p.div_hw);
+      const unsigned rem = mm - b * (unsigned)HWo;
+      const int oh = (int)fdiv(rem, p.div_w);
+      const int ow = (int)rem - oh * p.Wout;
+      // branch-free tap geometry: stride-2 (mode 1) multiplies, the fused upsample (mode 3) shifts
+      const int th = oh * gmul + b_dr[j] - pad, tw = ow * gmul + b_ds[j] - pad;
+      ok = ok && (unsigned)th < (unsigned)hlim && (unsigned)tw < (unsigned)wlim;
+      const int ih = th >> gshift, iw = tw >> gshift;
+      const void* src =
+          ok ? (const void*)(p.X + ((long)b * p.Hin * p.Win + (long)ih * p.Win + iw) * p.ldx + b_c[j]) : (const void*)zero;
+      glds16_tn(src, Bb + (wave * T2_BJ + j) * 1024);
+    }
+    mcur += T2_MS;
+  };
+
+  f32x4 acc[5][JT];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < JT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  typedef __attribute__((ext_vector_type(8))) short short8v;
+
+  auto compute = [&](int stage) {
+    const char* Ab = smem + stage * T2_STAGE;
+    const char* Bb = Ab + T2_A_BYTES;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      const int r0 = ms * 32 + 4 * g + q, r1 = r0 + 16;
+      bf16x8 a[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int ch = wa * 10 + i * 2 + (pp >> 1);
+        short4v t0 = lds_tr16_b64(Ab + r0 * T2_SA + ((ch ^ swA(r0)) << 4) + 8 * (pp & 1));
+        short4v t1 = lds_tr16_b64(Ab + r1 * T2_SA + ((ch ^ swA(r1)) << 4) + 8 * (pp & 1));
+        short8v v = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+        a[i] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {  // B fragments in two halves: keeps the kernel under 256 VGPRs
+        bf16x8 b[JT / 2];
+#pragma unroll
+        for (int jj = 0; jj < JT / 2; ++jj) {
+          const int ch = wb * (JT * 2) + (jh * (JT / 2) + jj) * 2 + (pp >> 1);
+          short4v t0 = lds_tr16_b64(Bb + r0 * T2_SB + ((ch ^ swB<T2_BK>(r0)) << 4) + 8 * (pp & 1));
+          short4v t1 = lds_tr16_b64(Bb + r1 * T2_SB + ((ch ^ swB<T2_BK>(r1)) << 4) + 8 * (pp & 1));
+          short8v v = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+          b[jj] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+          for (int jj = 0; jj < JT / 2; ++jj)
+            acc[i][jh * (JT / 2) + jj] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[jj], acc[i][jh * (JT / 2) + jj], 0, 0, 0);
+      }
+    }
+  };
+
+  issue(0);
+  __syncthreads();
+  for (int t = 0; t < nsteps; ++t) {
+    if (t + 1 < nsteps) issue((t + 1) & 1);
+    compute(t & 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const int kc = k0 + wb * (16 * JT) + j * 16 + (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + wa * 80 + i * 16 + (lane >> 4) * 4 + e;
+        if (n < p.N && kc < p.Kt) unsafeAtomicAdd(p.dW + (long)n * p.Kt + kc, acc[i][j][e]);
+      }
+    }
+}
+
+template <int BK>
+int launch_tn2(GemmTN2Params p, hipStream_t stream) {
+  constexpr int SMEM = 2 * (T2_A_BYTES + T2_MS * BK * 2);
+  p.tiles_n = (p.N + T2_BN - 1) / T2_BN;
+  p.tiles_k = (p.Kt + BK - 1) / BK;
+  const int tiles = p.tiles_n * p.tiles_k;
+  // One 512-thread workgroup per CU.  Pick the pixel split so that the grid is (nearly) a whole number of
+  // 256-CU rounds: among split counts giving >= 512 pixels per workgroup and <= ~1024 workgroups take the
+  // smallest one whose last round is >= 90 % full (fewer splits = less atomic traffic); else the fullest.
+  const int max_splits = p.M / 512 > 0 ? p.M / 512 : 1;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int k = 1; k <= max_splits && (long)tiles * k <= 1280; ++k) {
+    const long blocks = (long)tiles * k;
+    const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      best = k;
+    }
+    if (eff >= 0.9 && blocks >= 256) {
+      best = k;
+      break;
+    }
+  }
+  int mps = (p.M + best - 1) / best;
+  mps = ((mps + T2_MS - 1) / T2_MS) * T2_MS;
+  p.splits = (p.M + mps - 1) / mps;
+  p.m_per_split = mps;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_tn2_kernel<BK>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
+        hipSuccess)
+      return DA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn2_kernel<BK>, dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+}  // namespace
+
+// Called by da_gemm_tn_wgrad (gemm_tn.hip) after argument validation.  variant 2: 320x256 tile, 3: 320x192 tile.
+int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X, long ldx, float* dW, int M, int N,
+                           int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, hipStream_t stream) {
+  GemmTN2Params p;
+  p.dY = (const bf16*)dY; p.X = (const bf16*)X; p.dW = dW;
+  p.lddy = lddy; p.ldx = ldx;
+  p.M = M; p.N = N; p.Cin = Cin; p.Kt = ksize * ksize * Cin;
+  p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.ksize = ksize; p.mode = mode;
+  p.div_hw = make_fastdiv((unsigned)(Hout * Wout));
+  p.div_w = make_fastdiv((unsigned)Wout);
+  p.div_cin = make_fastdiv((unsigned)Cin);
+  p.tiles_n = p.tiles_k = p.splits = p.m_per_split = 0;
+  return variant == 2 ? launch_tn2<256>(p, stream) : launch_tn2<192>(p, stream);
+}

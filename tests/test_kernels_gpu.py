@@ -211,6 +211,49 @@ def test_wgrad(ops, dev, mode, B, H, Wd, C, Co):
     check(dW - 1.0, w_ohwi(w.grad), tol=2e-3, what=f'wgrad {mode}')
 
 
+@pytest.mark.parametrize('variant', [2, 3])
+@pytest.mark.parametrize('mode', ['s1', 's2', 'up', '1x1'])
+def test_wgrad_v2_forced(ops, dev, mode, variant):
+    """320x(256|192)x64 LDS-DMA wgrad kernels forced on: ragged N / K' / M tails, every gather mode, strided operands."""
+    ops.set_option('gemm_tn_variant', variant)
+    try:
+        B, H, Wd, C, Co = 3, 12, 12, 72, 200
+        xb = rnd(B * H * Wd, C + 24, dev=dev, seed=1).to(BF)
+        xv = xb[:, 8:8 + C]
+        x = from_nhwc(xv, B, H, Wd).float()
+        k = 1 if mode == '1x1' else 3
+        w = torch.zeros(Co, C, k, k, device=dev, requires_grad=True)
+        if mode == 's1':
+            y = F.conv2d(x, w, padding=1); g = ops.Geom.conv(B, H, Wd)
+        elif mode == 's2':
+            y = F.conv2d(x, w, stride=2, padding=1); g = ops.Geom.down(B, H, Wd)
+        elif mode == 'up':
+            y = F.conv2d(F.interpolate(x, scale_factor=2.0, mode='nearest'), w, padding=1); g = ops.Geom.up(B, H, Wd)
+        else:
+            y = F.conv2d(x, w); g = ops.Geom.conv(B, H, Wd, ksize=1)
+        dyb = rnd(y.shape[0] * y.shape[2] * y.shape[3], Co + 16, dev=dev, seed=2).to(BF)
+        dyv = dyb[:, 16:]
+        y.backward(from_nhwc(dyv, B, y.shape[2], y.shape[3]).float())
+        dW = torch.full((Co, k * k * C), 1.0, device=dev)
+        ops.gemm_tn_wgrad(dyv, xv, dW, g)
+        check(dW - 1.0, w_ohwi(w.grad), tol=2e-3, what=f'wgrad v2 {mode}')
+    finally:
+        ops.set_option('gemm_tn_variant', 0)
+
+
+@pytest.mark.parametrize('variant', [2, 3])
+def test_wgrad_v2_big(ops, dev, variant):
+    ops.set_option('gemm_tn_variant', variant)
+    try:
+        M, N, K = 9000, 640, 1280
+        dy = rnd(M, N, dev=dev, seed=1).to(BF); x = rnd(M, K, dev=dev, seed=2).to(BF)
+        dW = torch.zeros(N, K, device=dev)
+        ops.gemm_tn_wgrad(dy, x, dW, ops.Geom.linear(M))
+        check(dW, dy.float().t() @ x.float(), tol=1e-3, what='wgrad v2 linear')
+    finally:
+        ops.set_option('gemm_tn_variant', 0)
+
+
 def test_wgrad_linear_large_m(ops, dev):
     M, N, K = 5000, 136, 200
     dy = rnd(M, N, dev=dev, seed=1).to(BF)

@@ -46,9 +46,15 @@ def main(mb=64):
         t = timeit(lambda: ops.gemm_nt(x, w, y, g))
         dW = torch.zeros(Cout, k * k * Cin, device=dev)
         dy = torch.randn(M, Cout, device=dev).to(BF)
+        ops.set_option('gemm_tn_variant', 1)
+        t2a = timeit(lambda: ops.gemm_tn_wgrad(dy, x, dW, g))
+        ops.set_option('gemm_tn_variant', 2)
         t2 = timeit(lambda: ops.gemm_tn_wgrad(dy, x, dW, g))
+        ops.set_option('gemm_tn_variant', 3)
+        t3 = timeit(lambda: ops.gemm_tn_wgrad(dy, x, dW, g))
+        ops.set_option('gemm_tn_variant', 0)
         tiles = -(-M // 128) * -(-Cout // 128)
-        print(f'{name:28s} M={M:6d} N={Cout:5d} K={k*k*Cin:6d} tiles={tiles:5d} | nt v1 {fl/res[0]/1e9:6.1f} v2/160 {fl/res[1]/1e9:6.1f} v2/320 {fl/res[2]/1e9:6.1f} auto {fl/t/1e9:6.1f} TF/s | tn {t2*1e3:8.1f} us {fl/t2/1e9:7.1f} TF/s')
+        print(f'{name:28s} M={M:6d} N={Cout:5d} K={k*k*Cin:6d} tiles={tiles:5d} | nt v1 {fl/res[0]/1e9:6.1f} v2/160 {fl/res[1]/1e9:6.1f} v2/320 {fl/res[2]/1e9:6.1f} auto {fl/t/1e9:6.1f} TF/s | tn v1 {fl/t2a/1e9:6.1f} v2/256 {fl/t2/1e9:6.1f} v2/192 {fl/t3/1e9:6.1f} TF/s')
 
 
 if __name__ == '__main__':
