@@ -20,6 +20,7 @@ struct GemmTN2Params {
   const bf16* dY;
   const bf16* X;
   float* dW;
+  float* dbias;  // optional: dbias[n] += sum_m dY[m][n], produced by the tk == 0 workgroups
   long lddy, ldx;
   int M, N, Kt, Cin;
   int Hin, Win, Hout, Wout, ksize, mode;
@@ -151,6 +152,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
 
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   typedef __attribute__((ext_vector_type(8))) short short8v;
+  // bias gradient = dY^T . 1 : one extra MFMA per dY fragment against an all-ones B fragment (waves wb == 0 of
+  // the tk == 0 workgroups only), instead of a separate column-sum pass over dY
+  const bool do_bias = (p.dbias != nullptr) && (tk == 0) && (wb == 0);
+  f32x4 accb[5];
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int stage) {
     const char* Ab = smem + stage * T2_STAGE;
@@ -166,6 +176,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
         short4v t1 = lds_tr16_b64(Ab + r1 * T2_SA + ((ch ^ swA(r1)) << 4) + 8 * (pp & 1));
         short8v v = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
         a[i] = __builtin_bit_cast(bf16x8, v);
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
       }
 #pragma unroll
       for (int jh = 0; jh < 2; ++jh) {  // B fragments in two halves: keeps the kernel under 256 VGPRs
@@ -207,6 +221,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
         if (n < p.N && kc < p.Kt) unsafeAtomicAdd(p.dW + (long)n * p.Kt + kc, acc[i][j][e]);
       }
     }
+  if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + wa * 80 + i * 16 + (lane >> 4) * 4 + e;
+        if (n < p.N) unsafeAtomicAdd(p.dbias + n, accb[i][e]);
+      }
+  }
 }
 
 template <int BK>
@@ -252,10 +275,10 @@ int launch_tn2(GemmTN2Params p, hipStream_t stream) {
 }  // namespace
 
 // Called by da_gemm_tn_wgrad (gemm_tn.hip) after argument validation.  variant 2: 320x256 tile, 3: 320x192 tile.
-int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X, long ldx, float* dW, int M, int N,
-                           int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, hipStream_t stream) {
+int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias,
+                           int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, hipStream_t stream) {
   GemmTN2Params p;
-  p.dY = (const bf16*)dY; p.X = (const bf16*)X; p.dW = dW;
+  p.dY = (const bf16*)dY; p.X = (const bf16*)X; p.dW = dW; p.dbias = dbias;
   p.lddy = lddy; p.ldx = ldx;
   p.M = M; p.N = N; p.Cin = Cin; p.Kt = ksize * ksize * Cin;
   p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.ksize = ksize; p.mode = mode;

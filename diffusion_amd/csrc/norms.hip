@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* X, long ldx, co
 extern "C" long da_norm_scratch_floats(int B, int HW, int C) {
   // upper bound of partial-sum floats any norm / colsum entry point below needs
   long a = (long)B * pick_chunks(B, HW) * C * 2;
-  long b = 256L * C * 2;  // LayerNorm backward / colsum: <= 256 partial rows
+  long b = 1024L * C * 2;  // LayerNorm backward: <= 1024 partial rows; colsum: <= 256
   return a > b ? a : b;
 }
 
@@ -558,7 +558,7 @@ extern "C" int da_layernorm_bwd(const void* X, long ldx, const void* dY, long ld
     return DA_ERR_SHAPE;
   if (Radd && (ldr & 7)) return DA_ERR_SHAPE;
   int blocks = (M + 3) / 4;
-  if (blocks > 256) blocks = 256;
+  if (blocks > 1024) blocks = 1024;  // 4 waves each: >= 16 waves per CU in flight for this HBM-bound pass
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), (size_t)4 * C * 2 * sizeof(float), stream,
                      (const bf16*)X, ldx, (const bf16*)dY, lddy, (const bf16*)Radd, ldr, (bf16*)dX, lddx, gamma,
                      mean_rstd, scratch, M, C);

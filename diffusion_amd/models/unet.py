@@ -402,7 +402,8 @@ class UNetHIP(nn.Module):
         for lvl in range(4):
             need = max(need, ops.norm_scratch_floats(B, s * s, maxc))
             s = max(1, s // 2)
-        need = max(need, 256 * 8 * max(cfg.block_out_channels) * 2, 256 * self.tproj_total * 2, 4096)
+        need = max(need, 256 * 8 * max(cfg.block_out_channels) * 2, 256 * self.tproj_total * 2,
+                   1024 * max(cfg.block_out_channels) * 2, 4096)
         self._scratch = torch.empty(need, device=dev, dtype=F32)
         self._ss = torch.empty(B * maxc * 2, device=dev, dtype=F32)
         self._coef = torch.empty(B * cfg.norm_num_groups * 2, device=dev, dtype=F32)
@@ -446,9 +447,8 @@ class UNetHIP(nn.Module):
         """grads of y = x W^T + b : accumulates dW, db; returns dx."""
         m = self.M(key + '.weight')
         M = x.shape[0]
-        if bias:
-            ops.colsum_accum(dy, self.V(key + '.bias').g, self._scratch)
-        ops.gemm_tn_wgrad(dy, x, m.gw, Geom.linear(M))
+        ops.gemm_tn_wgrad(dy, x, m.gw, Geom.linear(M), dbias=self.V(key + '.bias').g if bias else None,
+                          scratch=self._scratch)
         if not need_dx:
             return None
         dx = dx_out if dx_out is not None else self._bf(M, m.C)
@@ -486,8 +486,7 @@ class UNetHIP(nn.Module):
         conv1, conv2 = self.M(p + '.conv1.weight'), self.M(p + '.conv2.weight')
         cout, cin = conv1.N, conv1.C
         g3 = Geom.conv(B, H, W)
-        ops.colsum_accum(dout, self.V(p + '.conv2.bias').g, self._scratch)
-        ops.gemm_tn_wgrad(dout, a2, conv2.gw, g3)
+        ops.gemm_tn_wgrad(dout, a2, conv2.gw, g3, dbias=self.V(p + '.conv2.bias').g, scratch=self._scratch)
         da2 = self._bf(M, cout)
         ops.gemm_nt(dout, conv2.wt, da2, g3)
         dh1 = self._gn_bwd(h1, da2, None, p + '.norm2', st2, B, HW, 1)
@@ -501,8 +500,7 @@ class UNetHIP(nn.Module):
         if (p + '.conv_shortcut.weight') in self._mats:
             sm = self.M(p + '.conv_shortcut.weight')
             g1 = Geom.conv(B, H, W, 1)
-            ops.colsum_accum(dout, self.V(p + '.conv_shortcut.bias').g, self._scratch)
-            ops.gemm_tn_wgrad(dout, x, sm.gw, g1)
+            ops.gemm_tn_wgrad(dout, x, sm.gw, g1, dbias=self.V(p + '.conv_shortcut.bias').g, scratch=self._scratch)
             dxs = self._bf(M, cin)
             ops.gemm_nt(dout, sm.wt, dxs, g1)
         else:
@@ -723,8 +721,7 @@ class UNetHIP(nn.Module):
                 h, a, st, B, S = sv
                 m = self.M('conv_out.weight')
                 g3 = Geom.conv(B, S, S)
-                ops.colsum_accum(dpred, self.V('conv_out.bias').g, self._scratch)
-                ops.gemm_tn_wgrad(dpred, a, m.gw, g3)
+                ops.gemm_tn_wgrad(dpred, a, m.gw, g3, dbias=self.V('conv_out.bias').g, scratch=self._scratch)
                 da = self._bf(B * S * S, m.C)
                 ops.gemm_nt(dpred, m.wt, da, g3)
                 dh = self._gn_bwd(h, da, None, 'conv_norm_out', st, B, S * S, 1)
@@ -738,8 +735,7 @@ class UNetHIP(nn.Module):
                 key, x, B, r = sv
                 lo = off(key + '.weight')
                 m = self.M(key + '.weight')
-                ops.colsum_accum(dh, self.V(key + '.bias').g, self._scratch)
-                ops.gemm_tn_wgrad(dh, x, m.gw, Geom.up(B, r, r))
+                ops.gemm_tn_wgrad(dh, x, m.gw, Geom.up(B, r, r), dbias=self.V(key + '.bias').g, scratch=self._scratch)
                 dup = self._bf(B * 4 * r * r, m.C)
                 ops.gemm_nt(dh, m.wt, dup, Geom.conv(B, 2 * r, 2 * r))
                 dx = self._bf(B * r * r, m.C)
@@ -758,8 +754,7 @@ class UNetHIP(nn.Module):
                 key, x, B, r = sv
                 lo = off(key + '.weight')
                 m = self.M(key + '.weight')
-                ops.colsum_accum(dh, self.V(key + '.bias').g, self._scratch)
-                ops.gemm_tn_wgrad(dh, x, m.gw, Geom.down(B, r, r))
+                ops.gemm_tn_wgrad(dh, x, m.gw, Geom.down(B, r, r), dbias=self.V(key + '.bias').g, scratch=self._scratch)
                 dx = self._bf(B * r * r, m.C)
                 ops.gemm_nt(dh, m.wt, dx, Geom.down_dgrad(B, r, r))
                 dh = dx
@@ -767,8 +762,8 @@ class UNetHIP(nn.Module):
                 xt8, B, S = sv
                 tot = self._bf(*dh.shape)
                 ops.add(dh, dskip.pop(0), tot)
-                ops.colsum_accum(tot, self.V('conv_in.bias').g, self._scratch)
-                ops.gemm_tn_wgrad(tot, xt8, self.M('conv_in.weight').gw, Geom.conv(B, S, S))
+                ops.gemm_tn_wgrad(tot, xt8, self.M('conv_in.weight').gw, Geom.conv(B, S, S),
+                                  dbias=self.V('conv_in.bias').g, scratch=self._scratch)
                 lo = off('conv_in.weight')
             else:  # pragma: no cover
                 raise AssertionError(kind)
@@ -778,8 +773,8 @@ class UNetHIP(nn.Module):
         te0, te1, te1s, temb, tembs = self._temb_saved
         Bt = te0.shape[0]
         mt = self.M('time_emb_proj_all.weight')
-        ops.colsum_accum(self._dtproj, self.V('time_emb_proj_all.bias').g, self._scratch)
-        ops.gemm_tn_wgrad(self._dtproj, tembs, mt.gw, Geom.linear(Bt))
+        ops.gemm_tn_wgrad(self._dtproj, tembs, mt.gw, Geom.linear(Bt), dbias=self.V('time_emb_proj_all.bias').g,
+                          scratch=self._scratch)
         dtembs = self._bf(Bt, mt.C)
         ops.gemm_nt(self._dtproj, mt.wt, dtembs, Geom.linear(Bt))
         dtemb = self._bf(Bt, mt.C)

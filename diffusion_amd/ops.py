@@ -131,8 +131,8 @@ def gemm_nt(A, W, out, g: Geom, *, bias=None, rowbias=None, residual=None, alpha
     return out
 
 
-def gemm_tn_wgrad(dY, X, dW, g: Geom):
-    """dW[N, k*k*Cin] (fp32) += dY^T @ gather(X)."""
+def gemm_tn_wgrad(dY, X, dW, g: Geom, dbias=None, scratch=None):
+    """dW[N, k*k*Cin] (fp32) += dY^T @ gather(X);  optionally dbias[N] += column sums of dY (fused)."""
     dy_ptr, lddy = _mat(dY, BF16, 'dY')
     x_ptr, ldx = _mat(X, BF16, 'X')
     M, N = dY.shape
@@ -145,8 +145,10 @@ def gemm_tn_wgrad(dY, X, dW, g: Geom):
     if mode == 2:
         raise ValueError('wgrad has no mode 2')
     with _Timed('gemm_tn', 2.0 * M * N * g.ksize * g.ksize * Cin):
-        _lib.call('da_gemm_tn_wgrad', dy_ptr, lddy, x_ptr, ldx, dW.data_ptr(), M, N, Cin, g.Hin, g.Win, g.Hout,
-                  g.Wout, g.ksize, mode, _stream())
+        db = _vec(dbias, N, 'dbias') if dbias is not None else 0
+        sc = _f32buf(scratch, 256 * N * 2, 'scratch') if dbias is not None else 0
+        _lib.call('da_gemm_tn_wgrad', dy_ptr, lddy, x_ptr, ldx, dW.data_ptr(), db, sc, M, N, Cin, g.Hin, g.Win,
+                  g.Hout, g.Wout, g.ksize, mode, _stream())
 
 
 def attn_fwd(Q, K, V, O, L2, B, H, Nq, Nk, scale):
@@ -220,7 +222,7 @@ def layernorm_bwd(X, dY, Radd, dX, gamma, mean_rstd, dgamma, dbeta, scratch):
     r, ldr = _mat(Radd, BF16, 'Radd') if Radd is not None else (0, 0)
     M, C = X.shape
     _lib.call('da_layernorm_bwd', x, ldx, dy, lddy, r, ldr, dx, lddx, _vec(gamma, C), _f32buf(mean_rstd, 2 * M),
-              _vec(dgamma, C), _vec(dbeta, C), _f32buf(scratch, 256 * C * 2), M, C, _stream())
+              _vec(dgamma, C), _vec(dbeta, C), _f32buf(scratch, 1024 * C * 2), M, C, _stream())
 
 
 def colsum_accum(X, out, scratch):

@@ -47,9 +47,10 @@ int da_set_option(const char* key, int value);
 
 /* dW[N][ksize*ksize*Cin] += sum_m dY[m][n] * gather(X)[m][k]   (fp32, atomically accumulated).
  * Replaces the cuDNN/cuBLAS wgrad kernels autograd runs for the same layers (loss.backward() driven by
- * Composer).  modes 0, 1, 3 as above. */
-int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, int M, int N, int Cin, int Hin,
-                     int Win, int Hout, int Wout, int ksize, int mode, da_stream_t stream);
+ * Composer).  modes 0, 1, 3 as above.  If dbias != NULL, dbias[n] += sum_m dY[m][n] as well
+ * (fused into the large-tile kernel; the small-shape path uses da_colsum_accum with `scratch`, >= 256*N*2 floats). */
+int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, float* scratch, int M,
+                     int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, da_stream_t stream);
 
 /* softmax(Q K^T * scale) V for head_dim 64, heads at column offsets h*64 of Q/K/V/O; L2[B][H][Nq] receives the
  * per-row log2-sum-exp.  Replaces xformers memory_efficient_attention (models.py:109-111) / diffusers

@@ -207,8 +207,10 @@ def test_wgrad(ops, dev, mode, B, H, Wd, C, Co):
     dy = rnd(*y.shape, dev=dev, seed=2).to(BF)
     y.backward(dy.float())
     dW = torch.full((Co, k * k * C), 1.0, device=dev)  # accumulate onto existing content
-    ops.gemm_tn_wgrad(nhwc(dy), nhwc(x), dW, g)
+    db = torch.zeros(Co, device=dev)
+    ops.gemm_tn_wgrad(nhwc(dy), nhwc(x), dW, g, dbias=db, scratch=torch.empty(256 * Co * 2, device=dev))
     check(dW - 1.0, w_ohwi(w.grad), tol=2e-3, what=f'wgrad {mode}')
+    check(db, nhwc(dy).float().sum(0), tol=2e-3, what=f'wgrad dbias {mode}')
 
 
 @pytest.mark.parametrize('variant', [2, 3])
@@ -235,8 +237,10 @@ def test_wgrad_v2_forced(ops, dev, mode, variant):
         dyv = dyb[:, 16:]
         y.backward(from_nhwc(dyv, B, y.shape[2], y.shape[3]).float())
         dW = torch.full((Co, k * k * C), 1.0, device=dev)
-        ops.gemm_tn_wgrad(dyv, xv, dW, g)
+        db = torch.full((Co,), 2.0, device=dev)
+        ops.gemm_tn_wgrad(dyv, xv, dW, g, dbias=db, scratch=torch.empty(256 * Co * 2, device=dev))
         check(dW - 1.0, w_ohwi(w.grad), tol=2e-3, what=f'wgrad v2 {mode}')
+        check(db - 2.0, dyv.float().sum(0), tol=2e-3, what=f'wgrad v2 fused dbias {mode}')
     finally:
         ops.set_option('gemm_tn_variant', 0)
 
@@ -361,7 +365,7 @@ def test_layernorm(ops, dev, M, C):
     ref.backward(dy.float())
     dx = torch.empty(M, C, device=dev, dtype=BF)
     dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
-    scratch = torch.empty(256 * C * 2, device=dev)
+    scratch = torch.empty(1024 * C * 2, device=dev)
     ops.layernorm_bwd(x, dy, radd, dx, gamma, mr, dg, db, scratch)
     check(dx, xr.grad + radd.float(), what='ln dx')
     check(dg, gr.grad, tol=3e-3, what='ln dgamma')
