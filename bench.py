@@ -140,6 +140,7 @@ def main():
         }
         if prof:
             kern = {}
+            shapes = prof.pop('_shapes', [])
             for k, evs in prof.items():
                 ms = sum(s.elapsed_time(e) for s, e, _ in evs)
                 fl = sum(f for _, _, f in evs)
@@ -150,6 +151,14 @@ def main():
                                'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(gk['tflops'] / PEAK_BF16_TFLOPS, 4),
                                'avg_launch_us': gk['avg_us'], 'launches': gk['launches'], 'traffic': None}
             out['kernels'] = kern
+            if os.environ.get('BENCH_SHAPES'):
+                agg = {}
+                for s_, e_, f_, tag in shapes:
+                    a_ = agg.setdefault(tag, [0, 0.0, 0.0])
+                    a_[0] += 1; a_[1] += s_.elapsed_time(e_); a_[2] += f_
+                top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]
+                for tag, (n_, ms_, fl_) in top:
+                    print(f'  {str(tag):48s} n={n_:4d} ms={ms_:8.2f} TF/s={fl_ / ms_ / 1e9:7.1f}', file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -56,12 +56,15 @@ DEVINL bf16x8 pack8(const f32x16& x, int s) {
 DEVINL int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ------------------------------------------------------------------------------------------------
-// forward
+// forward.  Workgroup = 128 queries (4 waves x 32), 64-key tiles, LDS double-buffered (one barrier per tile),
+// next tile prefetched into registers while the current one is consumed.  Softmax per 64-key step:
+// p = exp2(fma(s, sc, -m*sc)) on RAW scores (sc > 0 keeps the max order), rescale of O only when some lane's
+// running max moved (wave-uniform branch), key masking only on the ragged tail tile.
 // ------------------------------------------------------------------------------------------------
+constexpr int FW_STAGE = 64 * 128 + 64 * TR_LD;
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[64 * 128 + 64 * TR_LD];
-  char* Ks = smem;
-  char* Vs = smem + 64 * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * FW_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
   const int b = blockIdx.z, hd = blockIdx.y;
@@ -91,7 +94,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       rv[i] = ok ? ld8(p.V + base * p.ldv + hd * 64 + lchunk * 8) : zero8();
     }
   };
-  auto store = [&]() {
+  auto store = [&](int st) {
+    char* Ks = smem + st * FW_STAGE;
+    char* Vs = Ks + 64 * 128;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int row = lrow + 32 * i;
@@ -101,52 +106,63 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   };
 
   load(0);
+  store(0);
+  __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    __syncthreads();
-    store();
-    __syncthreads();
     if (t + 1 < nt) load(t + 1);
+    const char* Ks = smem + (t & 1) * FW_STAGE;
+    const char* Vs = Ks + 64 * 128;
+    f32x16 s0, s1;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int kb = half * 32;
-      if (t * 64 + kb >= p.Nk) break;
-      f32x16 s;
+    for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[i] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + swz128(kb + r, 2 * ks + h));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-      }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        int key = t * 64 + kb + acc_row(i, lane);
-        s[i] = key < p.Nk ? s[i] * p.sc : -INFINITY;
-        mx = fmaxf(mx, s[i]);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);
-      const float alpha = exp2f(m - mn);
-      float ls = 0.f;
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Ks + swz128(r, 2 * ks + h));
+      bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Ks + swz128(32 + r, 2 * ks + h));
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
+    }
+    if (t * 64 + 64 > p.Nk) {  // ragged tail tile only
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        s[i] = exp2f(s[i] - mn);
-        ls += s[i];
-      }
-      l = l * alpha + ls;
-      m = mn;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-      bf16x8 pf[2] = {pack8(s, 0), pack8(s, 1)};
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 v0 = tr_frag(Vs, kb + 16 * s2, 0, lane);
-        bf16x8 v1 = tr_frag(Vs, kb + 16 * s2, 32, lane);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[s2], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[s2], o1, 0, 0, 0);
+        int key = t * 64 + acc_row(i, lane);
+        if (key >= p.Nk) s0[i] = -INFINITY;
+        if (key + 32 >= p.Nk) s1[i] = -INFINITY;
       }
     }
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (__any(mx > m)) {
+      const float mn = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m - mn) * p.sc);
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+      m = mn;
+    }
+    const float msc = -m * p.sc;
+    float ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s0[i] = __builtin_amdgcn_exp2f(fmaf(s0[i], p.sc, msc));
+      s1[i] = __builtin_amdgcn_exp2f(fmaf(s1[i], p.sc, msc));
+      ls += s0[i] + s1[i];
+    }
+    l += ls;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 pa = pack8(s0, s2), pb = pack8(s1, s2);
+      bf16x8 va0 = tr_frag(Vs, 16 * s2, 0, lane), va1 = tr_frag(Vs, 16 * s2, 32, lane);
+      bf16x8 vb0 = tr_frag(Vs, 32 + 16 * s2, 0, lane), vb1 = tr_frag(Vs, 32 + 16 * s2, 32, lane);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, pa, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, pa, o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb0, pb, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb1, pb, o1, 0, 0, 0);
+    }
+    if (t + 1 < nt) store((t + 1) & 1);
+    __syncthreads();
   }
   const float lt = l + __shfl_xor(l, 32, 64);
   const float inv = 1.0f / lt;
@@ -163,18 +179,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       *reinterpret_cast<bf16x4*>(op + 8 * rg + 4 * h) = a;
       *reinterpret_cast<bf16x4*>(op + 32 + 8 * rg + 4 * h) = c;
     }
-    if (h == 0) p.L2[((long)b * p.H + hd) * p.Nq + q] = m + log2f(lt);
+    if (h == 0) p.L2[((long)b * p.H + hd) * p.Nq + q] = m * p.sc + log2f(lt);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, query-major: dQ (and delta = rowsum(dO*O), stored for the dK/dV kernel)
+// backward, query-major: dQ (and delta = rowsum(dO*O), stored for the dK/dV kernel).  Same pipeline as forward.
 // ------------------------------------------------------------------------------------------------
+constexpr int DQ_STAGE = 2 * 64 * 128 + 64 * TR_LD;
+
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128 + 64 * TR_LD];
-  char* Ks = smem;
-  char* Vs = smem + 64 * 128;
-  char* Kt = smem + 2 * 64 * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * DQ_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
   const int b = blockIdx.z, hd = blockIdx.y;
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   }
   delta += __shfl_xor(delta, 32, 64);
   const long statidx = ((long)b * p.H + hd) * p.Nq + q;
-  const float L2q = qv ? p.L2[statidx] : 0.f;
+  const float nL2q = qv ? -p.L2[statidx] : 0.f;
   if (qv && h == 0) p.Delta[statidx] = delta;
 
   f32x16 d0, d1;
@@ -214,7 +229,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
       rv[i] = ok ? ld8(p.V + base * p.ldv + hd * 64 + lchunk * 8) : zero8();
     }
   };
-  auto store = [&]() {
+  auto store = [&](int st) {
+    char* Ks = smem + st * DQ_STAGE;
+    char* Vs = Ks + 64 * 128;
+    char* Kt = Ks + 2 * 64 * 128;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int row = lrow + 32 * i;
@@ -225,11 +243,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   };
 
   load(0);
+  store(0);
+  __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    __syncthreads();
-    store();
-    __syncthreads();
     if (t + 1 < nt) load(t + 1);
+    const char* Ks = smem + (t & 1) * DQ_STAGE;
+    const char* Vs = Ks + 64 * 128;
+    const char* Kt = Ks + 2 * 64 * 128;
+    const bool tail = t * 64 + 64 > p.Nk;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int kb = half * 32;
@@ -246,9 +267,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        int key = t * 64 + kb + acc_row(i, lane);
-        float pv = key < p.Nk ? exp2f(s[i] * p.sc - L2q) : 0.f;
+        float pv = __builtin_amdgcn_exp2f(fmaf(s[i], p.sc, nL2q));
         s[i] = pv * (dp[i] - delta);
+      }
+      if (tail) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (t * 64 + kb + acc_row(i, lane) >= p.Nk) s[i] = 0.f;
       }
       bf16x8 dsf[2] = {pack8(s, 0), pack8(s, 1)};
 #pragma unroll
@@ -259,6 +284,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, dsf[s2], d1, 0, 0, 0);
       }
     }
+    if (t + 1 < nt) store((t + 1) & 1);
+    __syncthreads();
   }
   if (qv) {
     bf16* op = p.dQ + ((long)b * p.Nq + q) * p.lddq + hd * 64;
@@ -277,16 +304,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, key-major: dK, dV.  Workgroup = 128 keys (4 waves x 32), sweeps all queries in 32-row tiles.
+// backward, key-major: dK, dV.  Workgroup = 128 keys (4 waves x 32), sweeps all queries in 32-row tiles
+// (LDS double-buffered, one barrier per tile).
 // ------------------------------------------------------------------------------------------------
+constexpr int KV_STAGE = 2 * 32 * 128 + 2 * 32 * TR_LD + 2 * 32 * 4;
+
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 32 * 128 + 2 * 32 * TR_LD + 2 * 32 * 4];
-  char* Qs = smem;                       // row-read image of the Q tile
-  char* Os = smem + 32 * 128;            // row-read image of the dO tile
-  char* Qt = smem + 2 * 32 * 128;        // transposed-read image of Q
-  char* Ot = Qt + 32 * TR_LD;            // transposed-read image of dO
-  float* Ls = reinterpret_cast<float*>(Ot + 32 * TR_LD);
-  float* Ds = Ls + 32;
+  __shared__ __attribute__((aligned(16))) char smem[2 * KV_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
   const int b = blockIdx.z, hd = blockIdx.y;
@@ -318,27 +342,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       int q2 = t * 32 + tid;
       bool ok2 = q2 < p.Nq;
       long si = ((long)b * p.H + hd) * p.Nq + q2;
-      rl = ok2 ? p.L2[si] : 0.f;
+      rl = ok2 ? -p.L2[si] : 0.f;
       rd = ok2 ? p.Delta[si] : 0.f;
     }
   };
-  auto store = [&]() {
+  auto store = [&](int st) {
+    char* Qs = smem + st * KV_STAGE;
+    char* Os = Qs + 32 * 128;
+    char* Qt = Qs + 2 * 32 * 128;
+    char* Ot = Qt + 32 * TR_LD;
+    float* Ls = reinterpret_cast<float*>(Ot + 32 * TR_LD);
     *reinterpret_cast<bf16x8*>(Qs + swz128(lrow, lchunk)) = rq;
     *reinterpret_cast<bf16x8*>(Os + swz128(lrow, lchunk)) = rdo;
     *reinterpret_cast<bf16x8*>(Qt + lrow * TR_LD + lchunk * 16) = rq;
     *reinterpret_cast<bf16x8*>(Ot + lrow * TR_LD + lchunk * 16) = rdo;
     if (tid < 32) {
       Ls[tid] = rl;
-      Ds[tid] = rd;
+      Ls[32 + tid] = rd;
     }
   };
 
   load(0);
+  store(0);
+  __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    __syncthreads();
-    store();
-    __syncthreads();
     if (t + 1 < nt) load(t + 1);
+    const char* Qs = smem + (t & 1) * KV_STAGE;
+    const char* Os = Qs + 32 * 128;
+    const char* Qt = Qs + 2 * 32 * 128;
+    const char* Ot = Qt + 32 * TR_LD;
+    const float* Ls = reinterpret_cast<const float*>(Ot + 32 * TR_LD);
+    const float* Ds = Ls + 32;
     f32x16 s, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -357,7 +391,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = rg * 4 + e;
-        float pv = exp2f(s[i] * p.sc - l4[e]);
+        float pv = __builtin_amdgcn_exp2f(fmaf(s[i], p.sc, l4[e]));
         pr[i] = pv;
         s[i] = pv * (dp[i] - d4[e]);
       }
@@ -376,6 +410,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt0, dsf[s2], dk0, 0, 0, 0);
       dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt1, dsf[s2], dk1, 0, 0, 0);
     }
+    if (t + 1 < nt) store((t + 1) & 1);
+    __syncthreads();
   }
   if (kv) {
     bf16* kp = p.dK + ((long)b * p.Nk + key) * p.lddk + hd * 64;

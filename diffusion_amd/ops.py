@@ -26,10 +26,10 @@ PROFILE = None
 
 
 class _Timed:
-    __slots__ = ('name', 'flops', 'start')
+    __slots__ = ('name', 'flops', 'start', 'tag')
 
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops, tag=None):
+        self.name, self.flops, self.tag = name, flops, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -41,6 +41,8 @@ class _Timed:
             end = torch.cuda.Event(enable_timing=True)
             end.record()
             PROFILE.setdefault(self.name, []).append((self.start, end, self.flops))
+            if self.tag is not None:
+                PROFILE.setdefault('_shapes', []).append((self.start, end, self.flops, (self.name,) + self.tag))
 
 
 def _mat(x: torch.Tensor, dtype=BF16, name='arg') -> Tuple[int, int]:
@@ -125,7 +127,7 @@ def gemm_nt(A, W, out, g: Geom, *, bias=None, rowbias=None, residual=None, alpha
         if tuple(residual.shape) != (M, N):
             raise ValueError('residual must be [M, N]')
     flops = 2.0 * M * N * K * (0.25 if g.mode == 2 else 1.0)  # mode 2: 3 of 4 taps are structurally zero
-    with _Timed('gemm_nt', flops):
+    with _Timed('gemm_nt', flops, (M, N, K, g.ksize, g.mode)):
         _lib.call('da_gemm_nt', a_ptr, lda, w_ptr, c_ptr, ldc, _vec(bias, N, 'bias'), rb_ptr, ldrb, r_ptr, ldr, M, N,
                   K, Cin, g.Hin, g.Win, g.Hout, g.Wout, g.ksize, g.mode, int(out_fp32), float(alpha), _stream())
     return out
@@ -144,7 +146,7 @@ def gemm_tn_wgrad(dY, X, dW, g: Geom, dbias=None, scratch=None):
     mode = g.mode
     if mode == 2:
         raise ValueError('wgrad has no mode 2')
-    with _Timed('gemm_tn', 2.0 * M * N * g.ksize * g.ksize * Cin):
+    with _Timed('gemm_tn', 2.0 * M * N * g.ksize * g.ksize * Cin, (M, N, g.ksize * g.ksize * Cin, g.ksize, g.mode)):
         db = _vec(dbias, N, 'dbias') if dbias is not None else 0
         sc = _f32buf(scratch, 256 * N * 2, 'scratch') if dbias is not None else 0
         _lib.call('da_gemm_tn_wgrad', dy_ptr, lddy, x_ptr, ldx, dW.data_ptr(), db, sc, M, N, Cin, g.Hin, g.Win,
@@ -159,7 +161,7 @@ def attn_fwd(Q, K, V, O, L2, B, H, Nq, Nk, scale):
     for t, n in ((Q, Nq), (O, Nq), (K, Nk), (V, Nk)):
         if tuple(t.shape) != (B * n, H * 64):
             raise ValueError(f'attention operand shape {tuple(t.shape)} != {(B * n, H * 64)}')
-    with _Timed('attn_fwd', 4.0 * B * H * Nq * Nk * 64):
+    with _Timed('attn_fwd', 4.0 * B * H * Nq * Nk * 64, (B, H, Nq, Nk, 0)):
         _lib.call('da_attn_fwd', q, ldq, k, ldk, v, ldv, o, ldo, _f32buf(L2, B * H * Nq, 'L2'), B, H, Nq, Nk,
                   float(scale), _stream())
 
@@ -175,7 +177,7 @@ def attn_bwd(Q, K, V, O, dO, L2, Delta, dQ, dK, dV, B, H, Nq, Nk, scale):
         if tuple(t.shape) != (B * n, H * 64):
             raise ValueError(f'{nm} shape {tuple(t.shape)} != {(B * n, H * 64)}')
         outs += list(_mat(t, BF16, nm))
-    with _Timed('attn_bwd', 8.0 * B * H * Nq * Nk * 64):
+    with _Timed('attn_bwd', 8.0 * B * H * Nq * Nk * 64, (B, H, Nq, Nk, 0)):
         _lib.call('da_attn_bwd', *ptrs, _f32buf(L2, B * H * Nq, 'L2'), _f32buf(Delta, B * H * Nq, 'Delta'), *outs, B,
                   H, Nq, Nk, float(scale), _stream())
 
