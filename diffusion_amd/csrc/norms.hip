@@ -218,6 +218,90 @@ __global__ void gn_bwd_finalize_kernel(const float* partial, const float* gamma,
   }
 }
 
+// ---- GroupNorm apply, forward and backward, "channel-stationary": a thread keeps its 8 channels' coefficients
+// in registers and walks pixels (same geometry as chan_reduce), instead of re-deriving per-element group indices
+// and re-loading statistics for every element.
+//   fwd:  y  = act(x*sc + sh)                      sc = rstd*gamma, sh = beta - mean*sc
+//   bwd:  dx = dz*sc + x*Q + R (+ Radd)            dz = dy*silu'(x*sc+sh) ; Q = -rstd^2*c2 ; R = -rstd*c1 + mean*rstd^2*c2
+struct GnApplyParams {
+  const bf16* X; const bf16* DY; const bf16* Radd; bf16* OUT;
+  const float* mean_rstd; const float* coef; const float* gamma; const float* beta;
+  long ldx, lddy, ldr, ldo;
+  int HW, C, G, cpg, nchunks, ppc, pxt, silu;
+};
+
+template <bool BWD>
+__global__ void gn_apply2_kernel(GnApplyParams p) {
+  const int tid = threadIdx.x;
+  const int vec0 = blockIdx.z * 512;
+  const int nvec = min(512, (p.C >> 3) - vec0);
+  const int lvec = tid % nvec, pl = tid / nvec;
+  if (pl >= p.pxt) return;
+  const int vec = vec0 + lvec;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * p.ppc;
+  const int p1 = min(p.HW, p0 + p.ppc);
+  float sc[8], sh[8], Q[8], R[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * vec + e;
+    const int g = c / p.cpg;
+    const float mu = p.mean_rstd[((long)b * p.G + g) * 2], rs = p.mean_rstd[((long)b * p.G + g) * 2 + 1];
+    sc[e] = rs * p.gamma[c];
+    sh[e] = p.beta[c] - mu * sc[e];
+    if (BWD) {
+      const float c1 = p.coef[((long)b * p.G + g) * 2], c2 = p.coef[((long)b * p.G + g) * 2 + 1];
+      Q[e] = -rs * rs * c2;
+      R[e] = -rs * c1 + mu * rs * rs * c2;
+    }
+  }
+  for (int pix = p0 + pl; pix < p1; pix += p.pxt) {
+    const long row = (long)b * p.HW + pix;
+    const bf16x8 x = ld8(p.X + row * p.ldx + 8 * vec);
+    bf16x8 o;
+    if (!BWD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float z = fmaf(bf2f(x[e]), sc[e], sh[e]);
+        o[e] = f2bf(p.silu ? silu_f(z) : z);
+      }
+    } else {
+      const bf16x8 dy = ld8(p.DY + row * p.lddy + 8 * vec);
+      const bf16x8 ra = p.Radd ? ld8(p.Radd + row * p.ldr + 8 * vec) : zero8();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xf = bf2f(x[e]);
+        float dz = bf2f(dy[e]);
+        if (p.silu) dz *= dsilu_f(fmaf(xf, sc[e], sh[e]));
+        o[e] = f2bf(fmaf(dz, sc[e], fmaf(xf, Q[e], R[e])) + bf2f(ra[e]));
+      }
+    }
+    st8(p.OUT + row * p.ldo + 8 * vec, o);
+  }
+}
+
+int launch_gn_apply2(bool bwd, GnApplyParams& p, int B, hipStream_t stream) {
+  const int nvec_total = p.C >> 3;
+  const int zsplit = (nvec_total + 511) / 512;
+  const int nvec = nvec_total < 512 ? nvec_total : 512;
+  int pxt = 256 / nvec;
+  if (pxt < 1) pxt = 1;
+  if (pxt > p.HW) pxt = p.HW;
+  p.pxt = pxt;
+  // enough (image, pixel-chunk) workgroups to keep >= 8 waves per CU busy, >= 4 pixels per thread
+  int nch = (4096 + B * zsplit - 1) / (B * zsplit);
+  int maxc = p.HW / (4 * pxt);
+  if (nch > maxc) nch = maxc;
+  if (nch < 1) nch = 1;
+  p.nchunks = nch;
+  p.ppc = (p.HW + nch - 1) / nch;
+  dim3 grid(nch, B, zsplit), block(nvec * pxt);
+  if (bwd) hipLaunchKernelGGL(gn_apply2_kernel<true>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(gn_apply2_kernel<false>, grid, block, 0, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
 // dx = rstd * (dz*gamma - c1 - xhat*c2) (+ Radd)
 __global__ void gn_bwd_apply_kernel(const bf16* X, long ldx, const bf16* DY, long lddy, const bf16* Radd, long ldr,
                                     bf16* DX, long lddx, const float* mean_rstd, const float* coef,
@@ -464,13 +548,11 @@ extern "C" int da_groupnorm_fwd(const void* X, long ldx, void* Y, long ldy, cons
   hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(B), dim3(256), (size_t)(2 * C + 2 * G) * sizeof(float), stream,
                      scratch, gamma, beta, mean_rstd, scale_shift, C, G, C / G, p.nchunks, HW, eps);
   DA_CHECK_LAUNCH();
-  const long total_vec = (long)B * HW * (C >> 3);
-  int blocks = (int)((total_vec + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16*)X, ldx, (bf16*)Y, ldy,
-                     scale_shift, HW, C, total_vec, silu);
-  DA_CHECK_LAUNCH();
-  return DA_OK;
+  GnApplyParams ap = {};
+  ap.X = (const bf16*)X; ap.ldx = ldx; ap.OUT = (bf16*)Y; ap.ldo = ldy;
+  ap.mean_rstd = mean_rstd; ap.gamma = gamma; ap.beta = beta;
+  ap.HW = HW; ap.C = C; ap.G = G; ap.cpg = C / G; ap.silu = silu;
+  return launch_gn_apply2(false, ap, B, stream);
 }
 
 extern "C" int da_groupnorm_bwd(const void* X, long ldx, const void* dY, long lddy, const void* Radd, long ldr,
@@ -494,14 +576,12 @@ extern "C" int da_groupnorm_bwd(const void* X, long ldx, const void* dY, long ld
   hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, scratch,
                      B * p.nchunks, C, dbeta, dgamma, 1);
   DA_CHECK_LAUNCH();
-  const long total_vec = (long)B * HW * (C >> 3);
-  int blocks = (int)((total_vec + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16*)X, ldx, (const bf16*)dY,
-                     lddy, (const bf16*)Radd, ldr, (bf16*)dX, lddx, mean_rstd, coef, gamma, beta, HW, C, G, C / G,
-                     total_vec, silu);
-  DA_CHECK_LAUNCH();
-  return DA_OK;
+  GnApplyParams ap = {};
+  ap.X = (const bf16*)X; ap.ldx = ldx; ap.DY = (const bf16*)dY; ap.lddy = lddy; ap.Radd = (const bf16*)Radd; ap.ldr = ldr;
+  ap.OUT = (bf16*)dX; ap.ldo = lddx;
+  ap.mean_rstd = mean_rstd; ap.coef = coef; ap.gamma = gamma; ap.beta = beta;
+  ap.HW = HW; ap.C = C; ap.G = G; ap.cpg = C / G; ap.silu = silu;
+  return launch_gn_apply2(true, ap, B, stream);
 }
 
 extern "C" int da_colsum_accum(const void* X, long ldx, float* out, float* scratch, int M, int C,
