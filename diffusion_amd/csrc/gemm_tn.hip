@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNParams p) {
 // large-tile LDS-DMA variant (gemm_tn_v2.hip)
 int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias,
                            int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, hipStream_t stream);
-int g_tn_variant = 0;  // 0 auto, 1 force v1 (128x128x32), 2 / 3 force v2 (320x256x64 / 320x192x64); da_set_option
+int g_tn_variant = 0;  // 0 auto, 1 force v1 (128x128x32), 2 force v2 (320x192x64); da_set_option
 
 extern "C" int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias,
                                 float* scratch, int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize,

@@ -47,7 +47,7 @@ DEVINL void glds16_tn(const void* gsrc, char* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int T2_BK>  // output tile columns (k'): 256 or 192
+template <int T2_BK>  // output tile columns (k'): 192 (256 also fits the swizzle scheme but spills registers)
 __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   constexpr int T2_SB = T2_BK * 2;
   constexpr int T2_B_BYTES = T2_MS * T2_SB;
@@ -114,6 +114,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     b_ds[j] = s;
   }
 
+  // pixel coordinates of each X-chunk's row, advanced incrementally by 64 rows per stage (no per-step division)
+  int x_b[T2_BJ], x_oh[T2_BJ], x_ow[T2_BJ];
+#pragma unroll
+  for (int j = 0; j < T2_BJ; ++j) {
+    const unsigned mm = (unsigned)(m_begin + b_row[j]);
+    const unsigned bb = fdiv(mm, p.div_hw);
+    const unsigned rem = mm - bb * (unsigned)HWo;
+    x_b[j] = (int)bb;
+    x_oh[j] = (int)fdiv(rem, p.div_w);
+    x_ow[j] = (int)rem - x_oh[j] * p.Wout;
+  }
+  const int step_ow = T2_MS % p.Wout, step_oh = (T2_MS / p.Wout) % p.Hout, step_b = T2_MS / HWo;
+
   int mcur = m_begin;
   auto issue = [&](int stage) {
     char* Ab = smem + stage * T2_STAGE;
@@ -128,11 +141,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     for (int j = 0; j < T2_BJ; ++j) {
       const int m = mcur + b_row[j];
       bool ok = b_ok[j] && m < m_end;
-      const unsigned mm = ok ? (unsigned)m : 0u;
-      const unsigned b = fdiv(mm, p.div_hw);
-      const unsigned rem = mm - b * (unsigned)HWo;
-      const int oh = (int)fdiv(rem, p.div_w);
-      const int ow = (int)rem - oh * p.Wout;
+      const int b = x_b[j], oh = x_oh[j], ow = x_ow[j];
+      x_ow[j] += step_ow;
+      if (x_ow[j] >= p.Wout) { x_ow[j] -= p.Wout; x_oh[j] += 1; }
+      x_oh[j] += step_oh;
+      if (x_oh[j] >= p.Hout) { x_oh[j] -= p.Hout; x_b[j] += 1; }
+      x_b[j] += step_b;
       // branch-free tap geometry: stride-2 (mode 1) multiplies, the fused upsample (mode 3) shifts
       const int th = oh * gmul + b_dr[j] - pad, tw = ow * gmul + b_ds[j] - pad;
       ok = ok && (unsigned)th < (unsigned)hlim && (unsigned)tw < (unsigned)wlim;
@@ -274,7 +288,7 @@ int launch_tn2(GemmTN2Params p, hipStream_t stream) {
 
 }  // namespace
 
-// Called by da_gemm_tn_wgrad (gemm_tn.hip) after argument validation.  variant 2: 320x256 tile, 3: 320x192 tile.
+// Called by da_gemm_tn_wgrad (gemm_tn.hip) after argument validation.
 int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias,
                            int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, hipStream_t stream) {
   GemmTN2Params p;
@@ -286,5 +300,6 @@ int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X
   p.div_w = make_fastdiv((unsigned)Wout);
   p.div_cin = make_fastdiv((unsigned)Cin);
   p.tiles_n = p.tiles_k = p.splits = p.m_per_split = 0;
-  return variant == 2 ? launch_tn2<256>(p, stream) : launch_tn2<192>(p, stream);
+  (void)variant;  // the 320x256 instantiation (160 accumulators) spills on gfx950 and lost to 320x192 everywhere
+  return launch_tn2<192>(p, stream);
 }

@@ -42,7 +42,7 @@ int da_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const 
 
 /* tuning / test hook: "gemm_nt_variant" = 0 auto, 1 force the 128x128 kernel, 4 / 5 force the 256x128 / 256x160
  * LDS-DMA kernel where eligible (Cin % 64 == 0); "gemm_tn_variant" = 0 auto, 1 force the 128x128x32 wgrad kernel,
- * 2 force the 320x256x64 LDS-DMA wgrad kernel.  Returns DA_ERR_SHAPE for unknown keys. */
+ * 2 force the 320x192x64 LDS-DMA wgrad kernel.  Returns DA_ERR_SHAPE for unknown keys. */
 int da_set_option(const char* key, int value);
 
 /* dW[N][ksize*ksize*Cin] += sum_m dY[m][n] * gather(X)[m][k]   (fp32, atomically accumulated).

@@ -213,10 +213,10 @@ def test_wgrad(ops, dev, mode, B, H, Wd, C, Co):
     check(db, nhwc(dy).float().sum(0), tol=2e-3, what=f'wgrad dbias {mode}')
 
 
-@pytest.mark.parametrize('variant', [2, 3])
+@pytest.mark.parametrize('variant', [2])
 @pytest.mark.parametrize('mode', ['s1', 's2', 'up', '1x1'])
 def test_wgrad_v2_forced(ops, dev, mode, variant):
-    """320x(256|192)x64 LDS-DMA wgrad kernels forced on: ragged N / K' / M tails, every gather mode, strided operands."""
+    """320x192x64 LDS-DMA wgrad kernel forced on: ragged N / K' / M tails, every gather mode, strided operands."""
     ops.set_option('gemm_tn_variant', variant)
     try:
         B, H, Wd, C, Co = 3, 12, 12, 72, 200
@@ -245,7 +245,7 @@ def test_wgrad_v2_forced(ops, dev, mode, variant):
         ops.set_option('gemm_tn_variant', 0)
 
 
-@pytest.mark.parametrize('variant', [2, 3])
+@pytest.mark.parametrize('variant', [2])
 def test_wgrad_v2_big(ops, dev, variant):
     ops.set_option('gemm_tn_variant', variant)
     try:

@@ -50,8 +50,7 @@ def main(mb=64):
         t2a = timeit(lambda: ops.gemm_tn_wgrad(dy, x, dW, g))
         ops.set_option('gemm_tn_variant', 2)
         t2 = timeit(lambda: ops.gemm_tn_wgrad(dy, x, dW, g))
-        ops.set_option('gemm_tn_variant', 3)
-        t3 = timeit(lambda: ops.gemm_tn_wgrad(dy, x, dW, g))
+        t3 = t2
         ops.set_option('gemm_tn_variant', 0)
         tiles = -(-M // 128) * -(-Cout // 128)
         print(f'{name:28s} M={M:6d} N={Cout:5d} K={k*k*Cin:6d} tiles={tiles:5d} | nt v1 {fl/res[0]/1e9:6.1f} v2/160 {fl/res[1]/1e9:6.1f} v2/320 {fl/res[2]/1e9:6.1f} auto {fl/t/1e9:6.1f} TF/s | tn v1 {fl/t2a/1e9:6.1f} v2/256 {fl/t2/1e9:6.1f} v2/192 {fl/t3/1e9:6.1f} TF/s')
