@@ -84,11 +84,13 @@ def init_distributed_from_env(device_index: Optional[int] = None):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if torch.cuda.is_available():
-        torch.cuda.set_device(local if device_index is None else device_index)
+        # one rank per GPU; (DA_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path on a 1-GPU box)
+        n = torch.cuda.device_count()
+        torch.cuda.set_device((local if device_index is None else device_index) % max(n, 1))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get('DA_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         kw = {}
         if backend == 'nccl':
             kw['device_id'] = torch.device('cuda', torch.cuda.current_device())
