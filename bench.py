@@ -11,7 +11,7 @@ per-GPU batch is fixed, global batch = 256*N (2048 at N=8 = the reference's conf
 text embeddings, as the reference dataloader yields them) are resident in HBM before the timed region; timestep and
 noise draws are inside it, as in the reference's forward.  Weights are torch-default random init (seed 17).
 Prints ONE JSON line on rank 0 (see README / task contract), including `roofline` for the dominant kernel
-(gemm_nt_kernel: all conv / linear forward + dgrad contractions) and a `cpu_baseline` (oracle port on host cores).
+(the 256x320-tile implicit-GEMM gemm_nt2_kernel<8,5,2,4>: conv / linear forward + dgrad contractions) and a `cpu_baseline` (oracle port on host cores).
 """
 import argparse
 import json
@@ -146,8 +146,9 @@ def main():
                 fl = sum(f for _, _, f in evs)
                 kern[k] = {'launches': len(evs), 'ms': round(ms, 2), 'avg_us': round(1000 * ms / len(evs), 2),
                            'tflops': round(fl / ms / 1e9, 1) if ms > 0 else None}
-            gk = kern['gemm_nt']
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel', 'achieved': gk['tflops'],
+            dom = max((k for k in kern if k.startswith('gemm_nt')), key=lambda k: kern[k]['ms'])
+            gk = kern[dom]
+            out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': gk['tflops'],
                                'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(gk['tflops'] / PEAK_BF16_TFLOPS, 4),
                                'avg_launch_us': gk['avg_us'], 'launches': gk['launches'], 'traffic': None}
             out['kernels'] = kern

@@ -247,6 +247,21 @@ int da_gemm_nt_v2_dispatch(int variant, const void* A, long lda, const void* W, 
 extern int g_tn_variant;  // gemm_tn.hip
 static int g_nt_variant = 0;  // 0 auto, 1 force v1 (128x128), 4 / 5 force v2 with BN 128 / 160 (when eligible)
 
+// 1 -> gemm_nt_kernel (128x128), 4 / 5 / 10 -> gemm_nt2_kernel with BN 128 / 160 / 320
+static int pick_nt_variant(int M, int N, int Cin) {
+  if (Cin % 64 != 0) return 1;
+  if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10) return g_nt_variant;
+  if (g_nt_variant != 0) return 1;
+  // one 512-thread workgroup per CU: pick the largest tile that still keeps most of the 256 CUs busy
+  const long tm = (M + 255) / 256;
+  if (N % 320 == 0 && tm * (N / 320) >= 160) return 10;
+  if (N % 160 == 0 && tm * (N / 160) >= 200) return 5;
+  if (N % 160 != 0 && tm * ((N + 127) / 128) >= 200) return 4;
+  return 1;
+}
+
+extern "C" int da_gemm_nt_variant_for(int M, int N, int Cin) { return pick_nt_variant(M, N, Cin); }
+
 extern "C" int da_set_option(const char* key, int value) {
   if (key && !strcmp(key, "gemm_nt_variant")) {
     g_nt_variant = value;
@@ -273,19 +288,7 @@ extern "C" int da_gemm_nt(const void* A, long lda, const void* W, void* C, long 
   if (R && (ldr & 7)) return DA_ERR_SHAPE;
   if (rowbias && (ldrb & 7)) return DA_ERR_SHAPE;
   {
-    const bool eligible = (Cin % 64 == 0);
-    int variant = 1;
-    if (eligible) {
-      if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10) {
-        variant = g_nt_variant;
-      } else if (g_nt_variant == 0) {
-        // one 512-thread workgroup per CU: pick the largest tile that still keeps most of the 256 CUs busy
-        const long tm = (M + 255) / 256;
-        if (N % 320 == 0 && tm * (N / 320) >= 160) variant = 10;
-        else if (N % 160 == 0 && tm * (N / 160) >= 200) variant = 5;
-        else if (N % 160 != 0 && tm * ((N + 127) / 128) >= 200) variant = 4;
-      }
-    }
+    const int variant = pick_nt_variant(M, N, Cin);
     if (variant != 1)
       return da_gemm_nt_v2_dispatch(variant, A, lda, W, C, ldc, bias, rowbias, ldrb, R, ldr, M, N, K, Cin, Hin, Win,
                                     Hout, Wout, ksize, mode, out_fp32, alpha, stream);

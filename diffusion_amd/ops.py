@@ -127,7 +127,12 @@ def gemm_nt(A, W, out, g: Geom, *, bias=None, rowbias=None, residual=None, alpha
         if tuple(residual.shape) != (M, N):
             raise ValueError('residual must be [M, N]')
     flops = 2.0 * M * N * K * (0.25 if g.mode == 2 else 1.0)  # mode 2: 3 of 4 taps are structurally zero
-    with _Timed('gemm_nt', flops, (M, N, K, g.ksize, g.mode)):
+    name = 'gemm_nt'
+    if PROFILE is not None:
+        v = _lib.load().da_gemm_nt_variant_for(M, N, Cin)
+        name = {1: 'gemm_nt_kernel', 4: 'gemm_nt2_kernel<4,4,4,2>', 5: 'gemm_nt2_kernel<4,5,4,2>',
+                10: 'gemm_nt2_kernel<8,5,2,4>'}[v]
+    with _Timed(name, flops, (M, N, K, g.ksize, g.mode)):
         _lib.call('da_gemm_nt', a_ptr, lda, w_ptr, c_ptr, ldc, _vec(bias, N, 'bias'), rb_ptr, ldrb, r_ptr, ldr, M, N,
                   K, Cin, g.Hin, g.Win, g.Hout, g.Wout, g.ksize, g.mode, int(out_fp32), float(alpha), _stream())
     return out

@@ -44,6 +44,9 @@ int da_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const 
  * LDS-DMA kernel where eligible (Cin % 64 == 0); "gemm_tn_variant" = 0 auto, 1 force the 128x128x32 wgrad kernel,
  * 2 force the 320x192x64 LDS-DMA wgrad kernel.  Returns DA_ERR_SHAPE for unknown keys. */
 int da_set_option(const char* key, int value);
+/* which kernel da_gemm_nt dispatches to for (M, N, Cin): 1 = gemm_nt_kernel (128x128 tile), 4 / 5 / 10 =
+ * gemm_nt2_kernel with a 256x128 / 256x160 / 256x320 tile (profiling labels only) */
+int da_gemm_nt_variant_for(int M, int N, int Cin);
 
 /* dW[N][ksize*ksize*Cin] += sum_m dY[m][n] * gather(X)[m][k]   (fp32, atomically accumulated).
  * Replaces the cuDNN/cuBLAS wgrad kernels autograd runs for the same layers (loss.backward() driven by
