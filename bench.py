@@ -73,6 +73,9 @@ def main():
     ap.add_argument('--microbatch', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--full-pipeline', action='store_true',
+                    help='BASELINE cfg 3: precomputed_latents=false - frozen VAE-encode + CLIP text-encode on PyTorch-ROCm '
+                         '(random-init fp16 encoders, synthetic images / token ids) inside the timed step')
     a = ap.parse_args()
 
     from diffusion_amd.parallel import init_distributed_from_env
@@ -91,12 +94,17 @@ def main():
     mb = a.microbatch or {32: 256, 64: 64, 96: 16}[S]
     name = 'stabilityai/stable-diffusion-2' if S == 96 else 'stabilityai/stable-diffusion-2-base'
     torch.manual_seed(17 + rank)
-    model = stable_diffusion_2(model_name=name, pretrained=False, precomputed_latents=True, fsdp=False, seed=17)
+    model = stable_diffusion_2(model_name=name, pretrained=False, precomputed_latents=not a.full_pipeline, fsdp=False,
+                               seed=17)
     opt = FusedAdamW(lr=1e-4, weight_decay=0.01, unet=model.unet)
     trainer = Trainer(model, train_dataloader=None, optimizers=opt, max_duration='1ba', device_train_microbatch_size=mb)
     g = torch.Generator().manual_seed(1000 + rank)
-    batch = {'image_latents': torch.randn(B, 4, S, S, generator=g).half().to(dev),
-             'caption_latents': torch.randn(B, 77, 1024, generator=g).half().to(dev)}
+    if a.full_pipeline:
+        batch = {'image': (torch.rand(B, 3, 8 * S, 8 * S, generator=g) * 2 - 1).to(dev),
+                 'captions': torch.randint(0, 49408, (B, 77), generator=g).to(dev)}
+    else:
+        batch = {'image_latents': torch.randn(B, 4, S, S, generator=g).half().to(dev),
+                 'caption_latents': torch.randn(B, 77, 1024, generator=g).half().to(dev)}
 
     def sync():
         torch.cuda.synchronize()
@@ -125,7 +133,9 @@ def main():
     if rank == 0:
         ips = B * world * a.steps / dt
         out = {
-            'metric': f'U-Net training images/sec @{S * 8} (SD-2-base U-Net, precomputed latents 4x{S}x{S})',
+            'metric': (f'U-Net training images/sec @{S * 8} ({"SD-2.1-768-v" if S == 96 else "SD-2-base"} U-Net, ' +
+                       (f'online VAE+CLIP encode, images 3x{8 * S}x{8 * S})' if a.full_pipeline else
+                        f'precomputed latents 4x{S}x{S})')),
             'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(1000 * dt / a.steps, 2), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': (round(ips / README_8xA100[S], 3) if (world == 8 and S in README_8xA100) else None),

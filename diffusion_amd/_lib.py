@@ -40,7 +40,7 @@ SIGNATURES = {
     'da_timestep_embed': [_ll, _vp, _i, _i, _vp],
     'da_add_noise': [_fp, _fp, _ll, _fp, _fp, _vp, _fp, _i, _i, _i, _vp],
     'da_mse_loss': [_fp, _fp, _vp, _fp, _fp, _l, _f, _f, _i, _vp],
-    'da_adamw': [_fp, _fp, _fp, _fp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp],
+    'da_adamw': [_fp, _fp, _fp, _fp, _vp, _fp, _f, _l, _f, _f, _f, _f, _f, _i, _f, _vp],
     'da_cast_f32_bf16': [_fp, _vp, _l, _vp],
     'da_transpose_weight': [_vp, _vp, _i, _i, _i, _vp],
 }

@@ -212,8 +212,9 @@ __global__ void mse_finalize_kernel(const float* partial, int n, float* loss, fl
 }
 
 // ---- fused AdamW (torch.optim.AdamW semantics), flat buffers; writes the bf16 compute shadow
-__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* shadow, long n, float lr, float b1,
-                             float b2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2, float gscale) {
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* shadow, float* ema, float ema_s,
+                             long n, float lr, float b1, float b2, float eps, float wd, float inv_bc1,
+                             float inv_sqrt_bc2, float gscale) {
   GRID_STRIDE(i4, (n + 3) / 4) {
     long i = i4 * 4;
     if (i + 3 < n) {
@@ -231,6 +232,12 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, bf16*
         pp[e] = w;
         sh[e] = f2bf(w);
       }
+      if (ema) {  // EMA of the weights fused into the same pass (ema = s*ema + (1-s)*w_new)
+        f32x4 ee = *reinterpret_cast<f32x4*>(ema + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ee[e] = ema_s * ee[e] + (1.f - ema_s) * pp[e];
+        *reinterpret_cast<f32x4*>(ema + i) = ee;
+      }
       *reinterpret_cast<f32x4*>(p + i) = pp;
       *reinterpret_cast<f32x4*>(m + i) = mm;
       *reinterpret_cast<f32x4*>(v + i) = vv;
@@ -243,6 +250,7 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, bf16*
         float vj = b2 * v[j] + (1.f - b2) * gr * gr;
         w -= lr * inv_bc1 * mj / (sqrtf(vj) * inv_sqrt_bc2 + eps);
         p[j] = w; m[j] = mj; v[j] = vj; shadow[j] = f2bf(w);
+        if (ema) ema[j] = ema_s * ema[j] + (1.f - ema_s) * w;
       }
     }
   }
@@ -389,15 +397,17 @@ extern "C" int da_mse_loss(const float* pred, const float* target, void* dpred, 
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
-extern "C" int da_adamw(float* p, const float* g, float* m, float* v, void* shadow, long n, float lr, float beta1,
-                        float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s) {
+extern "C" int da_adamw(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_smoothing,
+                        long n, float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale,
+                        hipStream_t s) {
   DA_CLEAR_ERR();
   if (n <= 0 || step <= 0) return DA_ERR_SHAPE;
-  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) || ((uintptr_t)shadow & 7))
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) || ((uintptr_t)shadow & 7))
     return DA_ERR_SHAPE;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(pw_blocks((n + 3) / 4)), dim3(PW_BLOCK), 0, s, p, g, m, v, (bf16*)shadow, n,
+  hipLaunchKernelGGL(adamw_kernel, dim3(pw_blocks((n + 3) / 4)), dim3(PW_BLOCK), 0, s, p, g, m, v, (bf16*)shadow, ema,
+                     ema_smoothing, n,
                      lr, beta1, beta2, eps, wd, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
   DA_CHECK_LAUNCH();
   return DA_OK;

@@ -27,7 +27,6 @@ TARGET_PREFIX_ALIASES = [
     ('composer.callbacks.', 'diffusion_amd.trainer.NoOpCallback'),
     ('composer.loggers.', 'diffusion_amd.trainer.NoOpCallback'),
     ('composer.algorithms.', 'diffusion_amd.trainer.NoOpCallback'),
-    ('diffusion_amd.algorithms.', 'diffusion_amd.trainer.NoOpCallback'),
 ]
 
 _INTERP = re.compile(r'\$\{([^}]+)\}')

@@ -336,14 +336,17 @@ def mse_loss(pred, target, dpred, loss, scratch, total_pix, grad_coef, weight, a
               _f32buf(scratch, 1024), total_pix, float(grad_coef), float(weight), int(accumulate), _stream())
 
 
-def adamw(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, grad_scale):
+def adamw(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, grad_scale, ema=None, ema_smoothing=0.0):
     n = p.numel()
     for z in (p, g, m, v):
         if z.dtype != F32 or not z.is_contiguous() or z.numel() != n:
             raise ValueError('adamw: fp32 contiguous flat buffers of equal size required')
     if shadow.dtype != BF16 or shadow.numel() != n:
         raise ValueError('adamw: shadow')
-    _lib.call('da_adamw', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(), n, float(lr),
+    if ema is not None and (ema.dtype != F32 or not ema.is_contiguous() or ema.numel() != n):
+        raise ValueError('adamw: ema buffer')
+    _lib.call('da_adamw', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(),
+              ema.data_ptr() if ema is not None else 0, float(ema_smoothing), n, float(lr),
               float(beta1), float(beta2), float(eps), float(wd), int(step), float(grad_scale), _stream())
 
 

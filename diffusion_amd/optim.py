@@ -20,6 +20,9 @@ class FusedAdamW(torch.optim.Optimizer):
         # torch.optim bookkeeping (param_groups / state_dict) over a single flat tensor
         super().__init__([unet.master], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0
+        self.ema = None            # flat fp32 EMA of the weights (set by algorithms.ema.EMA)
+        self.ema_smoothing = 0.0
+        self.ema_update_this_step = False
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -27,7 +30,8 @@ class FusedAdamW(torch.optim.Optimizer):
         u = self.unet
         u.opt_step += 1
         ops.adamw(u.master, u.grad, u.exp_avg, u.exp_avg_sq, u.shadow, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
-                  g['weight_decay'], u.opt_step, self.grad_scale)
+                  g['weight_decay'], u.opt_step, self.grad_scale,
+                  ema=self.ema if self.ema_update_this_step else None, ema_smoothing=self.ema_smoothing)
         u.refresh_transposed()
 
     def zero_grad(self, set_to_none: bool = False):

@@ -42,7 +42,13 @@ def train(config) -> None:
         for _, call_conf in config.callbacks.items():
             if call_conf and '_target_' in call_conf:
                 callbacks.append(hydra.instantiate(call_conf))
-    # algorithms: low_precision_groupnorm / low_precision_layernorm are inherent to the kernels; EMA is a "next" row.
+    # algorithms: low_precision_groupnorm / low_precision_layernorm are inherent to the kernels (train.py:91-108);
+    # objects with a _target_ (EMA, SD-2-base-512.yaml:8-13) are instantiated like the reference does (train.py:86-90)
+    algorithms = []
+    if 'algorithms' in config and config.algorithms:
+        for _, ag_conf in config.algorithms.items():
+            if ag_conf and '_target_' in ag_conf:
+                algorithms.append(hydra.instantiate(ag_conf))
     scheduler = hydra.instantiate(config.scheduler) if config.get('scheduler') else None
 
     trainer_conf = dict(config.trainer)
@@ -53,7 +59,7 @@ def train(config) -> None:
         optimizers=optimizer,
         model=model,
         loggers=[],
-        algorithms=[],
+        algorithms=algorithms,
         schedulers=scheduler,
         callbacks=callbacks,
     )

@@ -99,6 +99,7 @@ class Trainer:
         self.microbatch = device_train_microbatch_size
         self.scheduler = schedulers
         self.callbacks: List[Callback] = [c for c in (callbacks or []) if isinstance(c, Callback)]
+        self.algorithms = [a for a in (algorithms or []) if hasattr(a, 'before_optimizer_step')]
         self.save_folder = save_folder
         self.save_interval = _parse_time(save_interval)[0] if save_interval else None
         self.batch_idx = 0
@@ -142,6 +143,8 @@ class Trainer:
             bpe = len(self.dataloader) if hasattr(self.dataloader, '__len__') else None
             self.optimizer.param_groups[0]['lr'] = self.base_lr * self.scheduler(self.batch_idx, bpe)
         self.optimizer.grad_scale = 1.0 / self.world
+        for a in self.algorithms:
+            a.before_optimizer_step(self)
         self.optimizer.step()
         return total
 

@@ -129,9 +129,10 @@ int da_mse_loss(const float* pred, const float* target, void* dpred, float* loss
                 float grad_coef, float weight, int accumulate, da_stream_t stream);
 
 /* torch.optim.AdamW step (train.py:33; SD-2-base-256.yaml:55-58) on flat fp32 master/moment buffers, gradient
- * pre-scaled by grad_scale; also writes the bf16 compute shadow. */
-int da_adamw(float* p, const float* g, float* m, float* v, void* shadow, long n, float lr, float beta1, float beta2,
-             float eps, float wd, int step, float grad_scale, da_stream_t stream);
+ * pre-scaled by grad_scale; also writes the bf16 compute shadow.  If ema != NULL the exponential moving average of
+ * the weights (diffusion/algorithms/ema.py:26-76 compute_ema: ema = s*ema + (1-s)*w) is updated in the same pass. */
+int da_adamw(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_smoothing, long n,
+             float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale, da_stream_t stream);
 
 int da_cast_f32_bf16(const float* src, void* dst, long n, da_stream_t stream);
 

@@ -487,6 +487,9 @@ def test_adamw_and_cast(ops, dev):
         ops.adamw(p, g, m, v, sh, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, 0.5)
         assert (p - pr.data).abs().max().item() < 2e-6, step
     assert torch.equal(sh, p.to(BF))
+    ema = p.clone(); before = p.clone()
+    ops.adamw(p, g, m, v, sh, 1e-3, 0.9, 0.999, 1e-8, 0.01, 4, 0.5, ema=ema, ema_smoothing=0.9)
+    assert torch.allclose(ema, 0.9 * before + 0.1 * p, atol=1e-6)  # compute_ema (ema.py:26-76) on the updated weights
     d = torch.empty(n, device=dev, dtype=BF)
     ops.cast_f32_bf16(p, d)
     assert torch.equal(d, p.to(BF))

@@ -32,3 +32,25 @@ def test_yaml_driven_training(dev, tmp_path):
     assert torch.allclose(trainer.model.unet.master, before)
     thr = [d for d in trainer.logs if 'throughput/samples_per_sec' in d]
     assert thr and thr[-1]['throughput/samples_per_sec'] > 0
+
+
+def test_ema_algorithm(dev):
+    from diffusion_amd import hydra_lite as h
+    from diffusion_amd.train import train
+    cfg = h.load_config(os.path.join(ROOT, 'yamls', 'hydra-yamls', 'SD-2-base-512.yaml'), [
+        'batch_size=4', 'model.model_name=tiny', 'trainer.max_duration=5ba', 'trainer.device_train_microbatch_size=4',
+        'dataset.train_dataset.num_workers=0', 'dataset.train_dataset.text_dim=128', 'dataset.train_dataset.resize_size=64',
+        'dataset.train_dataset.num_samples=4', 'algorithms.ema.ema_start=2ba', 'algorithms.ema.smoothing=0.5',
+        'optimizer.lr=1.0e-3', 'scheduler.t_warmup=0ba'])
+    assert h.resolve_target(cfg.algorithms.ema._target_).__name__ == 'EMA'
+    # replay the recursion on the host: EMA starts from the weights after batch 3's... (first update at batch 3)
+    trainer = train(cfg)
+    ema = trainer.algorithms[0]
+    assert ema.ema_started and trainer.optimizer.ema is not None
+    w = trainer.model.unet.master
+    assert not torch.equal(trainer.optimizer.ema, w)           # lags behind the live weights
+    live = w.clone(); avg = trainer.optimizer.ema.clone()
+    ema.swap_params(trainer)
+    assert torch.equal(trainer.model.unet.master, avg) and torch.equal(trainer.optimizer.ema, live)
+    ema.swap_params(trainer)
+    assert torch.equal(trainer.model.unet.master, live)
