@@ -145,33 +145,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int stage) {
+  auto compute_half = [&](int stage, int s) {
     const char* Ab = smem + stage * STAGE;
     const char* Bb = Ab + A_BYTES;
+    bf16x8 a[MT], b[NT];
+    const int chunk = s * 4 + (lane >> 4);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 a[MT], b[NT];
-      const int chunk = s * 4 + (lane >> 4);
+    for (int i = 0; i < MT; ++i)
+      a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2(wm * (16 * MT) + i * 16 + (lane & 15), chunk));
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2(wm * (16 * MT) + i * 16 + (lane & 15), chunk));
+    for (int j = 0; j < NT; ++j)
+      b[j] = *reinterpret_cast<const bf16x8*>(Bb + swz2(wn * (16 * NT) + j * 16 + (lane & 15), chunk));
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        b[j] = *reinterpret_cast<const bf16x8*>(Bb + swz2(wn * (16 * NT) + j * 16 + (lane & 15), chunk));
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   };
 
   const int nk = p.K / V2_BK;
   issue(0);
   __syncthreads();
   for (int t = 0; t < nk; ++t) {
+    // the address arithmetic + DMA issue of step t+1 sits BETWEEN the two MFMA halves of step t: every wave leaves
+    // the barrier at the same time, so issuing first would idle the matrix pipe of all four SIMDs during it
+    compute_half(t & 1, 0);
     if (t + 1 < nk) issue((t + 1) & 1);
-    compute(t & 1);
+    compute_half(t & 1, 1);
     __syncthreads();  // vmcnt(0): step t+1 has landed; barrier: everyone is done reading stage t
   }
 
