@@ -176,11 +176,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int stage) {
+  auto compute_half = [&](int stage, int ms) {
     const char* Ab = smem + stage * T2_STAGE;
     const char* Bb = Ab + T2_A_BYTES;
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
+    {
       const int r0 = ms * 32 + 4 * g + q, r1 = r0 + 16;
       bf16x8 a[5];
 #pragma unroll
@@ -219,8 +218,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   issue(0);
   __syncthreads();
   for (int t = 0; t < nsteps; ++t) {
+    // DMA issue of the next stage between the two MFMA halves (all waves leave the barrier together: issuing first
+    // would idle every SIMD's matrix pipe during the address arithmetic)
+    compute_half(t & 1, 0);
     if (t + 1 < nsteps) issue((t + 1) & 1);
-    compute(t & 1);
+    compute_half(t & 1, 1);
     __syncthreads();
   }
 
