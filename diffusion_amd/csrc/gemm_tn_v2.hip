@@ -234,7 +234,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int n = n0 + wa * 80 + i * 16 + (lane >> 4) * 4 + e;
-        if (n < p.N && kc < p.Kt) unsafeAtomicAdd(p.dW + (long)n * p.Kt + kc, acc[i][j][e]);
+        if (n < p.N && kc < p.Kt) {
+          float* dst = p.dW + (long)n * p.Kt + kc;
+          if (p.splits == 1) *dst += acc[i][j][e];  // sole owner of this tile: plain read-add-write
+          else unsafeAtomicAdd(dst, acc[i][j][e]);
+        }
       }
     }
   if (do_bias && (lane & 15) == 0) {
@@ -254,23 +258,34 @@ int launch_tn2(GemmTN2Params p, hipStream_t stream) {
   p.tiles_n = (p.N + T2_BN - 1) / T2_BN;
   p.tiles_k = (p.Kt + BK - 1) / BK;
   const int tiles = p.tiles_n * p.tiles_k;
-  // One 512-thread workgroup per CU.  Pick the pixel split so that the grid is (nearly) a whole number of
-  // 256-CU rounds: among split counts giving >= 512 pixels per workgroup and <= ~1024 workgroups take the
-  // smallest one whose last round is >= 90 % full (fewer splits = less atomic traffic); else the fullest.
-  const int max_splits = p.M / 512 > 0 ? p.M / 512 : 1;
+  // One 512-thread workgroup per CU; the pixel range is split into k parts so that tiles*k fills the 256 CUs.
+  //  * tiles >= 232 (>= 90 % of the CUs): k = 1 - the workgroup owns its tile, plain read-add-write, no atomics;
+  //  * otherwise the smallest k whose grid is (nearly) a whole number of 256-CU rounds (last round >= 90 % full),
+  //    capped so that the k extra fp32 atomic tile-writes (~1.3 TB/s chip-wide) stay below ~20 % of the GEMM time
+  //    (k <= M/6000) but never below one full round; fallback: the fullest grid within the cap.
   int best = 1;
-  double best_eff = 0.0;
-  for (int k = 1; k <= max_splits && (long)tiles * k <= 1280; ++k) {
-    const long blocks = (long)tiles * k;
-    const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
-    if (eff > best_eff + 1e-9) {
-      best_eff = eff;
-      best = k;
+  if (tiles < 232) {
+    int kcap = p.M / 6000;
+    const int one_round = (256 + tiles - 1) / tiles;
+    if (kcap < one_round) kcap = one_round;
+    const int max_splits = p.M / 512 > 0 ? p.M / 512 : 1;
+    if (kcap > max_splits) kcap = max_splits;
+    double best_eff = -1.0;
+    bool found = false;
+    for (int k = 1; k <= kcap; ++k) {
+      const long blocks = (long)tiles * k;
+      const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+      if (eff >= 0.9 && blocks >= 250) {
+        best = k;
+        found = true;
+        break;
+      }
+      if (eff >= best_eff - 1e-9) {  // ties -> more, shorter workgroups
+        best_eff = eff;
+        best = k;
+      }
     }
-    if (eff >= 0.9 && blocks >= 256) {
-      best = k;
-      break;
-    }
+    (void)found;
   }
   int mps = (p.M + best - 1) / best;
   mps = ((mps + T2_MS - 1) / T2_MS) * T2_MS;
