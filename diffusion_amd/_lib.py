@@ -14,9 +14,10 @@ _vp, _l, _i, _f, _fp, _ll = C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_void_p
 
 # name -> argtypes (must mirror include/diffusion_amd.h exactly)
 SIGNATURES = {
-    'da_gemm_nt': [_vp, _l, _vp, _vp, _l, _fp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    'da_gemm_nt': [_vp, _l, _vp, _vp, _l, _fp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _fp, _l,
+                   _vp],
     'da_set_option': [C.c_char_p, _i],
-    'da_gemm_nt_variant_for': [_i, _i, _i],
+    'da_gemm_nt_variant_for': [_i, _i, _i, _i, _l],
     'da_gemm_tn_wgrad': [_vp, _l, _vp, _l, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'da_attn_fwd': [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _fp, _i, _i, _i, _i, _f, _vp],
     'da_attn_bwd': [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _fp, _fp, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i,

@@ -239,16 +239,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
 }  // namespace
 
 // large-tile LDS-DMA variant (gemm_nt_v2.hip)
-int da_gemm_nt_v2_dispatch(int variant, const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
+int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
                            const void* rowbias, long ldrb, const void* R, long ldr, int M, int N, int K, int Cin,
                            int Hin, int Win, int Hout, int Wout, int ksize, int mode, int out_fp32, float alpha,
                            hipStream_t stream);
 
 extern int g_tn_variant;  // gemm_tn.hip
-static int g_nt_variant = 0;  // 0 auto, 1 force v1 (128x128), 4 / 5 force v2 with BN 128 / 160 (when eligible)
+static int g_nt_variant = 0;
+static int g_nt_splitk = 1;  // da_set_option("gemm_nt_splitk", 0/1)  // 0 auto, 1 force v1 (128x128), 4 / 5 force v2 with BN 128 / 160 (when eligible)
 
-// 1 -> gemm_nt_kernel (128x128), 4 / 5 / 10 -> gemm_nt2_kernel with BN 128 / 160 / 320
-static int pick_nt_variant(int M, int N, int Cin) {
+// 1 -> gemm_nt_kernel (128x128), 4 / 5 / 10 -> gemm_nt2_kernel with BN 128 / 160 / 320.  *splits > 1: split-K over
+// that many workgroups per tile (needs a workspace of splits*M*N floats) - used when the tile grid alone would
+// leave most of the 256 CUs idle (small M: low-resolution layers, small microbatches).
+static int pick_nt_variant(int M, int N, int K, int Cin, long ws_floats, int* splits) {
+  *splits = 1;
   if (Cin % 64 != 0) return 1;
   if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10) return g_nt_variant;
   if (g_nt_variant != 0) return 1;
@@ -257,14 +261,32 @@ static int pick_nt_variant(int M, int N, int Cin) {
   if (N % 320 == 0 && tm * (N / 320) >= 160) return 10;
   if (N % 160 == 0 && tm * (N / 160) >= 200) return 5;
   if (N % 160 != 0 && tm * ((N + 127) / 128) >= 200) return 4;
+  if (N % 320 == 0 && g_nt_splitk) {
+    const long tiles = tm * (N / 320);
+    const int nk = K / 64;
+    int s = (int)((256 + tiles - 1) / tiles);
+    if (s > 8) s = 8;
+    while (s > 1 && (nk / s < 8 || (long)s * M * N > ws_floats)) --s;  // >= 8 K-steps per split, workspace fits
+    if (s > 1 && tiles * s >= 96) {
+      *splits = s;
+      return 10;
+    }
+  }
   return 1;
 }
 
-extern "C" int da_gemm_nt_variant_for(int M, int N, int Cin) { return pick_nt_variant(M, N, Cin); }
+extern "C" int da_gemm_nt_variant_for(int M, int N, int K, int Cin, long ws_floats) {
+  int s;
+  return pick_nt_variant(M, N, K, Cin, ws_floats, &s);
+}
 
 extern "C" int da_set_option(const char* key, int value) {
   if (key && !strcmp(key, "gemm_nt_variant")) {
     g_nt_variant = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_splitk")) {
+    g_nt_splitk = value;
     return DA_OK;
   }
   if (key && !strcmp(key, "gemm_tn_variant")) {
@@ -277,7 +299,7 @@ extern "C" int da_set_option(const char* key, int value) {
 extern "C" int da_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
                           const void* rowbias, long ldrb, const void* R, long ldr, int M, int N, int K, int Cin,
                           int Hin, int Win, int Hout, int Wout, int ksize, int mode, int out_fp32, float alpha,
-                          hipStream_t stream) {
+                          float* splitk_ws, long splitk_ws_floats, hipStream_t stream) {
   DA_CLEAR_ERR();
   if (M <= 0 || N <= 0 || K <= 0) return DA_ERR_SHAPE;
   if ((N & 7) || (Cin & 7) || (K % Cin) || (lda & 7) || (ldc & 7)) return DA_ERR_SHAPE;
@@ -288,9 +310,10 @@ extern "C" int da_gemm_nt(const void* A, long lda, const void* W, void* C, long 
   if (R && (ldr & 7)) return DA_ERR_SHAPE;
   if (rowbias && (ldrb & 7)) return DA_ERR_SHAPE;
   {
-    const int variant = pick_nt_variant(M, N, Cin);
+    int splits = 1;
+    const int variant = pick_nt_variant(M, N, K, Cin, splitk_ws ? splitk_ws_floats : 0, &splits);
     if (variant != 1)
-      return da_gemm_nt_v2_dispatch(variant, A, lda, W, C, ldc, bias, rowbias, ldrb, R, ldr, M, N, K, Cin, Hin, Win,
+      return da_gemm_nt_v2_dispatch(variant, splits, splitk_ws, A, lda, W, C, ldc, bias, rowbias, ldrb, R, ldr, M, N, K, Cin, Hin, Win,
                                     Hout, Wout, ksize, mode, out_fp32, alpha, stream);
   }
   GemmNTParams p;

@@ -30,6 +30,8 @@ struct GemmNT2Params {
   int out_fp32;
   float alpha;
   int tiles_m, tiles_n;
+  int splits, ksteps_per_split;  // split-K: workgroup (tile, s) multiplies K-steps [s*kps, (s+1)*kps) into slab s
+  long slab_stride;              // elements between fp32 partial slabs (split-K only)
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
   const int wm = wave / WN, wn = wave % WN;
 
   const int nblk = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
+  const int split = blockIdx.x / nblk;  // splits of a tile are nblk workgroups apart
+  int bid = blockIdx.x - split * nblk;
   {
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
@@ -104,7 +107,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
     wsrc[j] = p.W + (long)(wval[j] ? n : 0) * p.K + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
   }
 
-  int tap = 0, c0 = 0, k0 = 0;
+  const int kstep_begin = split * p.ksteps_per_split;
+  const int nk_total = p.K / V2_BK;
+  const int nk = min(p.ksteps_per_split, nk_total - kstep_begin);
+  int k0 = kstep_begin * V2_BK;
+  int tap = k0 / p.Cin;
+  int c0 = k0 - tap * p.Cin;
   auto issue = [&](int stage) {
     char* Ab = smem + stage * STAGE;
     char* Bb = Ab + A_BYTES;
@@ -163,7 +171,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   };
 
-  const int nk = p.K / V2_BK;
   issue(0);
   __syncthreads();
   for (int t = 0; t < nk; ++t) {
@@ -197,6 +204,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
         if (m < p.M && n < p.N) {
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8]);
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8 + 4]);
+          if (p.splits > 1) {  // split-K partial: raw fp32 sums into this split's slab; finalize kernel does the epilogue
+            float* cp = reinterpret_cast<float*>(p.C) + split * p.slab_stride + (long)m * p.N + n;
+            *reinterpret_cast<f32x4*>(cp) = v0;
+            *reinterpret_cast<f32x4*>(cp + 4) = v1;
+            continue;
+          }
           float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
           if (p.bias) {
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -239,8 +252,51 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
   }
 }
 
+// split-K finalize: out[m][n] = alpha * sum_s slab[s][m][n] + bias[n] + rowbias[image(m)][n] + R[m][n]
+__global__ void splitk_finalize_kernel(GemmNT2Params p, const float* ws) {
+  const int nvec = p.N >> 3;
+  const long total = (long)p.M * nvec;
+  const int HWo = p.Hout * p.Wout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / nvec;
+    const int n = (int)(i - m * nvec) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.splits; ++s) {
+      const float* src = ws + s * p.slab_stride + m * p.N + n;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += a[e];
+        v[e + 4] += b[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
+    if (p.rowbias) {
+      const bf16x8 rbv = ld8(p.rowbias + (m / HWo) * p.ldrb + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(rbv[e]);
+    }
+    if (p.R) {
+      const bf16x8 rv = ld8(p.R + m * p.ldr + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
+    }
+    if (p.out_fp32) {
+      float* cp = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+      *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+      st8(reinterpret_cast<bf16*>(p.C) + m * p.ldc + n, o);
+    }
+  }
+}
+
 template <int MT, int NT, int WM, int WN>
-int launch_v2(const GemmNT2Params& p0, hipStream_t stream) {
+int launch_v2(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream) {
   GemmNT2Params p = p0;
   constexpr int BN = 16 * NT * WN;
   constexpr int SMEM = 2 * (V2_BM * V2_BK * 2 + BN * V2_BK * 2);
@@ -253,6 +309,24 @@ int launch_v2(const GemmNT2Params& p0, hipStream_t stream) {
       return DA_ERR_LAUNCH;
     attr_set = true;
   }
+  const int nk_total = p.K / V2_BK;
+  p.splits = splits > 1 ? splits : 1;
+  p.ksteps_per_split = (nk_total + p.splits - 1) / p.splits;
+  p.splits = (nk_total + p.ksteps_per_split - 1) / p.ksteps_per_split;  // no empty splits
+  p.slab_stride = (long)p.M * p.N;
+  if (p.splits > 1) {
+    GemmNT2Params pk = p;
+    pk.C = ws;  // partial slabs
+    hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(512), SMEM,
+                       stream, pk);
+    DA_CHECK_LAUNCH();
+    const long total = (long)p.M * (p.N >> 3);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3((int)blocks), dim3(256), 0, stream, p, (const float*)ws);
+    DA_CHECK_LAUNCH();
+    return DA_OK;
+  }
   hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(512), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
@@ -261,7 +335,7 @@ int launch_v2(const GemmNT2Params& p0, hipStream_t stream) {
 }  // namespace
 
 // Called by da_gemm_nt (gemm_nt.hip) after argument validation.  variant: 4 -> BN 128, 5 -> BN 160, 10 -> BN 320.
-int da_gemm_nt_v2_dispatch(int variant, const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
+int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
                            const void* rowbias, long ldrb, const void* R, long ldr, int M, int N, int K, int Cin,
                            int Hin, int Win, int Hout, int Wout, int ksize, int mode, int out_fp32, float alpha,
                            hipStream_t stream) {
@@ -273,6 +347,7 @@ int da_gemm_nt_v2_dispatch(int variant, const void* A, long lda, const void* W, 
   p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
   p.ksize = ksize; p.mode = mode; p.out_fp32 = out_fp32; p.alpha = alpha;
   p.tiles_m = p.tiles_n = 0;
-  if (variant == 10) return launch_v2<8, 5, 2, 4>(p, stream);
-  return variant == 5 ? launch_v2<4, 5, 4, 2>(p, stream) : launch_v2<4, 4, 4, 2>(p, stream);
+  p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
+  if (variant == 10) return launch_v2<8, 5, 2, 4>(p, splits, ws, stream);
+  return variant == 5 ? launch_v2<4, 5, 4, 2>(p, splits, ws, stream) : launch_v2<4, 4, 4, 2>(p, splits, ws, stream);
 }

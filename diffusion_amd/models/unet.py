@@ -408,6 +408,8 @@ class UNetHIP(nn.Module):
         self._ss = torch.empty(B * maxc * 2, device=dev, dtype=F32)
         self._coef = torch.empty(B * cfg.norm_num_groups * 2, device=dev, dtype=F32)
         self._delta = torch.empty(B * max(cfg.attention_head_dim) * S * S, device=dev, dtype=F32)
+        if ops.SPLITK_WS is None:  # 128 MiB fp32 slabs for split-K of small-M GEMMs (shared by all calls on the stream)
+            ops.SPLITK_WS = torch.empty(32 * 1024 * 1024, device=dev, dtype=F32)
         self._scratch_key = key
 
     def _bf(self, m, c):

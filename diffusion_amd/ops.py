@@ -20,6 +20,11 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# optional fp32 workspace for split-K (set by the owner of the compute, e.g. UNetHIP): da_gemm_nt splits the K loop
+# of small-M calls over several workgroups when this is available
+SPLITK_WS = None
+
+
 # bench.py instrumentation: when PROFILE is a dict, every launch of the named kernel family is bracketed by HIP
 # events on the launch stream and its algorithmic FLOPs are recorded: PROFILE[name] -> list of (start, end, flops)
 PROFILE = None
@@ -129,12 +134,14 @@ def gemm_nt(A, W, out, g: Geom, *, bias=None, rowbias=None, residual=None, alpha
     flops = 2.0 * M * N * K * (0.25 if g.mode == 2 else 1.0)  # mode 2: 3 of 4 taps are structurally zero
     name = 'gemm_nt'
     if PROFILE is not None:
-        v = _lib.load().da_gemm_nt_variant_for(M, N, Cin)
+        v = _lib.load().da_gemm_nt_variant_for(M, N, K, Cin, SPLITK_WS.numel() if SPLITK_WS is not None else 0)
         name = {1: 'gemm_nt_kernel', 4: 'gemm_nt2_kernel<4,4,4,2>', 5: 'gemm_nt2_kernel<4,5,4,2>',
                 10: 'gemm_nt2_kernel<8,5,2,4>'}[v]
     with _Timed(name, flops, (M, N, K, g.ksize, g.mode)):
         _lib.call('da_gemm_nt', a_ptr, lda, w_ptr, c_ptr, ldc, _vec(bias, N, 'bias'), rb_ptr, ldrb, r_ptr, ldr, M, N,
-                  K, Cin, g.Hin, g.Win, g.Hout, g.Wout, g.ksize, g.mode, int(out_fp32), float(alpha), _stream())
+                  K, Cin, g.Hin, g.Win, g.Hout, g.Wout, g.ksize, g.mode, int(out_fp32), float(alpha),
+                  SPLITK_WS.data_ptr() if SPLITK_WS is not None else 0,
+                  SPLITK_WS.numel() if SPLITK_WS is not None else 0, _stream())
     return out
 
 

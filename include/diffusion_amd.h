@@ -35,18 +35,21 @@ typedef struct ihipStream_t* da_stream_t; /* == hipStream_t */
  * their dgrad in backward.  K = ksize*ksize*Cin; W is [N][kh][kw][Cin]; M = B*Hout*Wout.
  * mode 0: stride 1 (pad 1 when ksize 3); 1: stride 2 pad 1 (Downsample2D); 2: dgrad of mode 1 (A = dY at
  * Hin x Win = half resolution); 3: 3x3 conv over the nearest-2x upsampled A (Upsample2D), Hout = 2*Hin.
- * out_fp32: C is float* (else bf16). */
+ * out_fp32: C is float* (else bf16).  splitk_ws (may be NULL): fp32 workspace of splitk_ws_floats elements; when the
+ * tile grid alone would leave most CUs idle (small M) the K loop is split over up to 8 workgroups per tile whose
+ * partial slabs (splits*M*N floats) are summed by a fused finalize pass. */
 int da_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const void* rowbias,
                long ldrb, const void* R, long ldr, int M, int N, int K, int Cin, int Hin, int Win, int Hout, int Wout,
-               int ksize, int mode, int out_fp32, float alpha, da_stream_t stream);
+               int ksize, int mode, int out_fp32, float alpha, float* splitk_ws, long splitk_ws_floats,
+               da_stream_t stream);
 
 /* tuning / test hook: "gemm_nt_variant" = 0 auto, 1 force the 128x128 kernel, 4 / 5 force the 256x128 / 256x160
  * LDS-DMA kernel where eligible (Cin % 64 == 0); "gemm_tn_variant" = 0 auto, 1 force the 128x128x32 wgrad kernel,
  * 2 force the 320x192x64 LDS-DMA wgrad kernel.  Returns DA_ERR_SHAPE for unknown keys. */
 int da_set_option(const char* key, int value);
-/* which kernel da_gemm_nt dispatches to for (M, N, Cin): 1 = gemm_nt_kernel (128x128 tile), 4 / 5 / 10 =
+/* which kernel da_gemm_nt dispatches to for (M, N, K, Cin) given a split-K workspace of that many floats: 1 = gemm_nt_kernel (128x128 tile), 4 / 5 / 10 =
  * gemm_nt2_kernel with a 256x128 / 256x160 / 256x320 tile (profiling labels only) */
-int da_gemm_nt_variant_for(int M, int N, int Cin);
+int da_gemm_nt_variant_for(int M, int N, int K, int Cin, long splitk_ws_floats);
 
 /* dW[N][ksize*ksize*Cin] += sum_m dY[m][n] * gather(X)[m][k]   (fp32, atomically accumulated).
  * Replaces the cuDNN/cuBLAS wgrad kernels autograd runs for the same layers (loss.backward() driven by

@@ -188,6 +188,30 @@ def test_gemm_nt_v2_variants(ops, dev, variant):
         ops.set_option('gemm_nt_variant', 0)
 
 
+def test_gemm_nt_splitk(ops, dev):
+    """small-M, long-K conv: auto dispatch picks the 256x320 tile with split-K (workspace given) - same result."""
+    B, H, Wd, C, Co = 8, 4, 4, 320, 320      # M = 128 -> 1 tile of 256x320; K = 2880 -> split over 5 workgroups
+    x = rnd(B, C, H, Wd, dev=dev, seed=1).to(BF)
+    w = rnd(Co, C, 3, 3, dev=dev, seed=2, scale=(9 * C)**-0.5).to(BF)
+    bias = rnd(Co, dev=dev, seed=3); rb = rnd(B, Co, dev=dev, seed=4).to(BF); R = rnd(B * H * Wd, Co, dev=dev, seed=5).to(BF)
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1) + rb.float()[:, :, None, None] + from_nhwc(R, B, H, Wd).float()
+    old = ops.SPLITK_WS
+    try:
+        ops.SPLITK_WS = torch.empty(8 * 128 * 320, device=dev)
+        o = torch.empty(B * H * Wd, Co, device=dev, dtype=BF)
+        ops.gemm_nt(nhwc(x), w_ohwi(w), o, ops.Geom.conv(B, H, Wd), bias=bias, rowbias=rb, residual=R)
+        check(from_nhwc(o, B, H, Wd), ref, what='split-K conv')
+        o32 = torch.empty(B * H * Wd, Co, device=dev, dtype=torch.float32)
+        ops.gemm_nt(nhwc(x), w_ohwi(w), o32, ops.Geom.conv(B, H, Wd), alpha=0.5)
+        check(from_nhwc(o32, B, H, Wd), 0.5 * F.conv2d(x.float(), w.float(), padding=1), tol=1e-5, what='split-K fp32')
+        ops.SPLITK_WS = None     # without a workspace the same call takes the unsplit path
+        o2 = torch.empty_like(o)
+        ops.gemm_nt(nhwc(x), w_ohwi(w), o2, ops.Geom.conv(B, H, Wd), bias=bias, rowbias=rb, residual=R)
+        check(from_nhwc(o2, B, H, Wd), ref, what='unsplit conv')
+    finally:
+        ops.SPLITK_WS = old
+
+
 # ------------------------------------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize('mode', ['s1', 's2', 'up', '1x1'])
 @pytest.mark.parametrize('B,H,Wd,C,Co', [(2, 12, 12, 64, 72), (3, 8, 8, 8, 320), (2, 16, 16, 320, 8)])
