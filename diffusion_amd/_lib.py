@@ -44,6 +44,7 @@ SIGNATURES = {
     'da_adamw': [_fp, _fp, _fp, _fp, _vp, _fp, _f, _l, _f, _f, _f, _f, _f, _i, _f, _vp],
     'da_cast_f32_bf16': [_fp, _vp, _l, _vp],
     'da_transpose_weight': [_vp, _vp, _i, _i, _i, _vp],
+    'da_transpose_weights_batched': [_vp, _vp, _vp, _i, _i, _vp],
 }
 _RESTYPES = {'da_norm_scratch_floats': C.c_long}
 

@@ -277,6 +277,40 @@ __global__ void transpose_weight_kernel(const bf16* src, bf16* dst, int N, int T
   }
 }
 
+// ---- all dgrad weight shadows in ONE launch: descriptor table {src_off, dst_off, N, T, C, first_block} per tensor
+struct TransposeDesc {
+  long src_off, dst_off;
+  int N, T, C, first_block;
+};
+__global__ void transpose_weights_batched_kernel(const bf16* src_base, bf16* dst_base, const TransposeDesc* desc,
+                                                 int ntensors) {
+  __shared__ bf16 tile[32][33];
+  // binary search: last tensor whose first_block <= blockIdx.x
+  int lo = 0, hi = ntensors - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const TransposeDesc d = desc[lo];
+  int b = blockIdx.x - d.first_block;
+  const int tc = (d.C + 31) / 32, tn = (d.N + 31) / 32;
+  const int t = b / (tc * tn);
+  b -= t * tc * tn;
+  const int n0 = (b / tc) * 32, c0 = (b % tc) * 32;
+  const bf16* src = src_base + d.src_off;
+  bf16* dst = dst_base + d.dst_off;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    int n = n0 + j, c = c0 + tx;
+    tile[j][tx] = (n < d.N && c < d.C) ? src[((long)n * d.T + t) * d.C + c] : (bf16)0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, n = n0 + tx;
+    if (c < d.C && n < d.N) dst[((long)c * d.T + (d.T - 1 - t)) * d.N + n] = tile[tx][j];
+  }
+}
+
 }  // namespace
 
 #define CHK8(x) if ((x) & 7) return DA_ERR_SHAPE
@@ -424,6 +458,16 @@ extern "C" int da_transpose_weight(const void* src, void* dst, int N, int T, int
   if (N <= 0 || T <= 0 || C <= 0) return DA_ERR_SHAPE;
   hipLaunchKernelGGL(transpose_weight_kernel, dim3((C + 31) / 32, (N + 31) / 32, T), dim3(256), 0, s,
                      (const bf16*)src, (bf16*)dst, N, T, C);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_transpose_weights_batched(const void* src_base, void* dst_base, const void* desc, int ntensors,
+                                            int total_blocks, hipStream_t s) {
+  DA_CLEAR_ERR();
+  if (ntensors <= 0 || total_blocks <= 0) return DA_ERR_SHAPE;
+  hipLaunchKernelGGL(transpose_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, s, (const bf16*)src_base,
+                     (bf16*)dst_base, (const TransposeDesc*)desc, ntensors);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

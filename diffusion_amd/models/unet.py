@@ -376,8 +376,19 @@ class UNetHIP(nn.Module):
         self.refresh_transposed()
 
     def refresh_transposed(self):
-        for m in self._mats.values():
-            ops.transpose_weight(m.w, m.wt, m.N, m.T, m.C)
+        """shadow [N][T][C] -> dgrad shadow [C][T-1-t][N] for every weight matrix, in one launch."""
+        if getattr(self, '_tdesc', None) is None:
+            import struct
+            recs, first = [], 0
+            for st in self.fp.storages.values():
+                if st.ntc is None:
+                    continue
+                N, T, C = st.ntc
+                recs.append(struct.pack('<qqiiii', st.off, st.toff, N, T, C, first))
+                first += T * ((N + 31) // 32) * ((C + 31) // 32)
+            self._tdesc = torch.frombuffer(bytearray(b''.join(recs)), dtype=torch.uint8).to(self.device_)
+            self._tdesc_n, self._tdesc_blocks = len(recs), first
+        ops.transpose_weights_batched(self.shadow, self.shadow_t, self._tdesc, self._tdesc_n, self._tdesc_blocks)
 
     def zero_grad(self, set_to_none: bool = False):  # type: ignore[override]
         self.grad.zero_()

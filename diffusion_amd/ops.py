@@ -367,3 +367,10 @@ def transpose_weight(src, dst, N, T, C):
     if src.dtype != BF16 or dst.dtype != BF16 or src.numel() != N * T * C or dst.numel() != N * T * C:
         raise ValueError('transpose_weight: bad args')
     _lib.call('da_transpose_weight', src.data_ptr(), dst.data_ptr(), N, T, C, _stream())
+
+
+def transpose_weights_batched(src_base, dst_base, desc, ntensors, total_blocks):
+    if src_base.dtype != BF16 or dst_base.dtype != BF16 or desc.dtype != torch.uint8 or not desc.is_cuda:
+        raise ValueError('transpose_weights_batched: bad args')
+    _lib.call('da_transpose_weights_batched', src_base.data_ptr(), dst_base.data_ptr(), desc.data_ptr(), int(ntensors),
+              int(total_blocks), _stream())

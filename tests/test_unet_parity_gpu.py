@@ -156,3 +156,17 @@ def test_full_sd2_base_forward_and_grads(dev):
                 worst = (c, k)
     assert math.sqrt(num / den) < 6e-2, math.sqrt(num / den)
     assert worst[0] > 0.97, worst
+
+
+def test_batched_transpose_matches_per_tensor(dev):
+    from diffusion_amd import ops
+    from diffusion_amd.models.unet import UNetConfig, UNetHIP
+    u = UNetHIP(UNetConfig.tiny(), seed=3)
+    got = u.shadow_t.clone()
+    u.shadow_t.zero_()
+    for m in u._mats.values():
+        ops.transpose_weight(m.w, m.wt, m.N, m.T, m.C)
+    assert torch.equal(got, u.shadow_t)
+    m = u.M('down_blocks.1.resnets.0.conv1.weight')
+    w = m.w.view(m.N, 3, 3, m.C).float()
+    assert torch.equal(m.wt.view(m.C, 3, 3, m.N).float(), w.flip(1, 2).permute(3, 1, 2, 0))
