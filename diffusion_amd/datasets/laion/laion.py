@@ -4,7 +4,8 @@
 ``StreamingLAIONDataset.__getitem__`` (:81-112): ``image`` 3xRxR fp32 in [-1,1], ``captions`` 77 int64,
 ``caption_latents`` 77x1024 fp16, ``image_latents`` 4x(R/8)x(R/8) fp16.  mosaicml-streaming (MDS) is not available
 here, so two backends exist:
-  * ``local`` pointing at a directory of ``*.npz`` shards with raw-fp16 columns ``caption_latents``,
+  * ``local`` pointing at an MDS directory (``index.json`` + ``shard.*.mds``, read by ``datasets/mds.py`` - the
+    reference's own precomputed-latent format) or at a directory of ``*.npz`` shards with raw-fp16 columns ``caption_latents``,
     ``latents_256`` / ``latents_512`` (the column names scripts/precompute_latents.py:252-272 writes) and
     optional ``captions``;
   * no ``remote``/``local`` (the YAML default: both empty) -> a seeded synthetic dataset of the same shapes
@@ -41,6 +42,39 @@ class SyntheticLAIONDataset(Dataset):
         }
         if self.with_images:
             out['image'] = torch.rand(3, self.image_size, self.image_size, generator=g) * 2 - 1
+        return out
+
+
+class MDSLatentDataset(Dataset):
+    """Precomputed-latent MDS shards (the reference's training data format).  Yields the reference's sample dict
+    (laion.py:102-112) minus the decoded JPEG: with latents present the image is never used by ``forward``
+    (stable_diffusion.py:157-158), and decoding it is the dominant host cost of the reference loader."""
+
+    def __init__(self, directory: str, image_size: int, tokenizer=None, caption_drop_prob: float = 0.0):
+        from ..mds import MDSDirectory
+        self.mds = MDSDirectory(directory)
+        self.image_size, self.tokenizer, self.caption_drop_prob = image_size, tokenizer, caption_drop_prob
+        self.col = f'latents_{image_size}'
+
+    def __len__(self):
+        return len(self.mds)
+
+    def __getitem__(self, index):
+        smp = self.mds.get(index, columns=('caption', 'caption_latents', self.col))
+        s = self.image_size // 8
+        lat = np.frombuffer(smp[self.col], dtype=np.float16)
+        if lat.size != 4 * s * s:
+            # the writer stores b'' when the source image is smaller than the resolution (precompute_latents.py:303-306)
+            raise IndexError(f'sample {index} has no {self.col}')
+        out = {'caption_latents': torch.from_numpy(np.frombuffer(smp['caption_latents'], dtype=np.float16).copy()).reshape(77, -1),
+               'image_latents': torch.from_numpy(lat.copy()).reshape(4, s, s)}
+        caption = '' if torch.rand(1) < self.caption_drop_prob else smp.get('caption', '')
+        if self.tokenizer is not None:
+            ids = self.tokenizer(caption, padding='max_length', max_length=self.tokenizer.model_max_length,
+                                 truncation=True)['input_ids']
+            out['captions'] = torch.tensor(ids)
+        else:
+            out['captions'] = torch.zeros(77, dtype=torch.int64)
         return out
 
 
@@ -101,7 +135,11 @@ def build_streaming_laion_dataloader(
     with_images = dataloader_kwargs.pop('synthetic_images', False)
     dirs = [d for d in (local or []) if d and os.path.isdir(d)]
     if dirs:
-        dataset = torch.utils.data.ConcatDataset([LocalLatentShards(d, resize_size) for d in dirs])
+        from ...models.text import build_tokenizer
+        tok = build_tokenizer(tokenizer_name_or_path if os.path.isdir(str(tokenizer_name_or_path)) else None)
+        parts = [MDSLatentDataset(d, resize_size, tok, caption_drop_prob) if os.path.exists(os.path.join(d, 'index.json'))
+                 else LocalLatentShards(d, resize_size) for d in dirs]
+        dataset = torch.utils.data.ConcatDataset(parts)
     else:
         dataset = SyntheticLAIONDataset(image_size=resize_size, caption_drop_prob=caption_drop_prob, text_dim=text_dim,
                                         with_images=with_images)

@@ -175,3 +175,38 @@ def test_metric_shim_and_dataloader_local(tmp_path):
     assert bt['image_latents'].shape == (3, 4, 32, 32) and bt['caption_latents'].shape == (3, 77, 1024)
     with pytest.raises(ValueError):
         build_streaming_laion_dataloader(remote=['a', 'b'], local=['a'], batch_size=1)
+
+
+def test_mds_reader_roundtrip(tmp_path):
+    """MDS shards with the column set of scripts/precompute_latents.py:252-272 (subset) -> dataloader batch dict."""
+    import numpy as np
+    from diffusion_amd.datasets.mds import MDSDirectory, write_mds
+    from diffusion_amd.datasets.laion.laion import build_streaming_laion_dataloader
+    rng = np.random.default_rng(0)
+    cols = {'punsafe': 'float64', 'caption': 'str', 'width': 'int32', 'height': 'int32', 'jpg': 'bytes', 'hash': 'int64',
+            'caption_latents': 'bytes', 'latents_256': 'bytes', 'latents_512': 'bytes'}
+    samples = []
+    for i in range(7):
+        samples.append({'punsafe': 0.1 * i, 'caption': f'a photo number {i} \u00e9', 'width': 300 + i, 'height': 280,
+                        'jpg': bytes(rng.integers(0, 255, 50 + i, dtype=np.uint8)), 'hash': -i,
+                        'caption_latents': rng.standard_normal((77, 1024)).astype(np.float16).tobytes(),
+                        'latents_256': rng.standard_normal((4, 32, 32)).astype(np.float16).tobytes(),
+                        'latents_512': b''})   # image smaller than 512: empty bytes (precompute_latents.py:305-306)
+    d = str(tmp_path / 'mds')
+    write_mds(d, cols, samples, samples_per_shard=3)   # 3 shards: 3 + 3 + 1
+    md = MDSDirectory(d)
+    assert len(md) == 7 and len(md.shards) == 3
+    for i in (0, 2, 3, 6):
+        got = md.get(i)
+        assert got['caption'] == samples[i]['caption'] and got['jpg'] == samples[i]['jpg']
+        assert int(got['width']) == 300 + i and int(got['hash']) == -i and abs(float(got['punsafe']) - 0.1 * i) < 1e-12
+        assert got['latents_256'] == samples[i]['latents_256'] and got['latents_512'] == b''
+    dl = build_streaming_laion_dataloader(remote=d, local=d, batch_size=3, resize_size=256, shuffle=False, num_workers=0)
+    b = next(iter(dl))
+    assert b['image_latents'].shape == (3, 4, 32, 32) and b['image_latents'].dtype == torch.float16
+    assert b['caption_latents'].shape == (3, 77, 1024) and b['captions'].shape == (3, 77)
+    ref = torch.from_numpy(np.frombuffer(samples[1]['latents_256'], np.float16).copy()).reshape(4, 32, 32)
+    assert torch.equal(b['image_latents'][1], ref)
+    dl512 = build_streaming_laion_dataloader(remote=d, local=d, batch_size=1, resize_size=512, num_workers=0)
+    with pytest.raises(IndexError):
+        next(iter(dl512))
