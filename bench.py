@@ -161,6 +161,16 @@ def main():
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': gk['tflops'],
                                'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(gk['tflops'] / PEAK_BF16_TFLOPS, 4),
                                'avg_launch_us': gk['avg_us'], 'launches': gk['launches'], 'traffic': None}
+            # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside the
+            # process); the committed summary of those passes over this same command is reported with its provenance
+            tp = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+            if S == 32 and os.path.exists(tp):
+                with open(tp) as f:
+                    pm = json.load(f)
+                key = {'gemm_nt2_kernel<8,5,2,4>': 'gemm_nt2<8,5,2,4>'}.get(dom)
+                if key in pm:
+                    out['roofline']['traffic'] = round(pm[key]['hbm_bytes_per_launch_corrected'])
+                    out['roofline']['traffic_source'] = 'profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)'
             out['kernels'] = kern
             if os.environ.get('BENCH_SHAPES'):
                 agg = {}
