@@ -357,3 +357,40 @@ def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
     denom = (v.sqrt() / math.sqrt(bc2)) + eps
     p = p - (lr / bc1) * m / denom
     return p, m, v
+
+
+# --------------------------------------------------------------------------------------------------
+# DDIM sampling with classifier-free guidance (stable_diffusion.py:354-379; diffusers DDIMScheduler restated:
+# eta = 0, set_alpha_to_one = False, steps_offset = 1 - SD-2 scheduler_config.json / models.py:146-158)
+# --------------------------------------------------------------------------------------------------
+def ddim_timesteps(num_inference_steps: int, num_train_timesteps: int = 1000, steps_offset: int = 1) -> Tensor:
+    ratio = num_train_timesteps // num_inference_steps
+    return (torch.arange(0, num_inference_steps) * ratio).flip(0) + steps_offset
+
+
+def ddim_sample(sd, cfg: UNetConfig, text_emb: Tensor, uncond_emb: Optional[Tensor], latents: Tensor,
+                num_inference_steps: int, guidance_scale: float, schedule: Optional[DDPMSchedule] = None) -> Tensor:
+    """Returns the final latents (before the 1/0.18215 rescale and VAE decode of stable_diffusion.py:379-380)."""
+    schedule = schedule or DDPMSchedule()
+    ac = schedule.alphas_cumprod.to(latents.dtype)
+    T = schedule.num_train_timesteps
+    do_cfg = guidance_scale > 1.0
+    emb = torch.cat([uncond_emb, text_emb]) if do_cfg else text_emb
+    for t in ddim_timesteps(num_inference_steps, T):
+        t = int(t)
+        x_in = torch.cat([latents] * 2) if do_cfg else latents
+        tt = torch.full((x_in.shape[0],), t, dtype=torch.int64)
+        eps = unet_forward(sd, cfg, x_in, tt, emb)
+        if do_cfg:
+            eu, et = eps.chunk(2)
+            eps = eu + guidance_scale * (et - eu)
+        prev_t = t - T // num_inference_steps
+        a_t = ac[t]
+        a_prev = ac[prev_t] if prev_t >= 0 else ac[0]
+        if cfg.prediction_type == 'v_prediction':
+            x0 = a_t.sqrt() * latents - (1 - a_t).sqrt() * eps
+            eps = a_t.sqrt() * eps + (1 - a_t).sqrt() * latents
+        else:
+            x0 = (latents - (1 - a_t).sqrt() * eps) / a_t.sqrt()
+        latents = a_prev.sqrt() * x0 + (1 - a_prev).sqrt() * eps
+    return latents
