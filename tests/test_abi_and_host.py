@@ -107,7 +107,7 @@ def test_hydra_lite(tmp_path):
                         ['batch_size=512', 'dataset.train_dataset.shuffle=false', 'trainer.max_duration=7ba'])
     assert cfg.dataset.train_batch_size == 512 and cfg.dataset.train_dataset.batch_size == 512
     assert cfg.dataset.train_dataset.shuffle is False and cfg.trainer.max_duration == '7ba'
-    assert cfg.trainer.seed == 17 and cfg.trainer.device_train_microbatch_size == 16
+    assert cfg.trainer.seed == 17 and cfg.trainer.device_train_microbatch_size == 'auto'
     assert h.resolve_target('diffusion.models.models.stable_diffusion_2').__module__ == 'diffusion_amd.models.models'
     assert h.resolve_target('composer.Trainer').__name__ == 'Trainer'
     assert h.resolve_target('torch.optim.AdamW').__name__ == 'FusedAdamW'
