@@ -61,11 +61,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave >> 1, wb = wave & 1;  // 4 waves along n (80 each) x 2 along k' (128 each)
 
+  // XCD-aware order: workgroups b, b+8, ... share an XCD (and its L2).  Each XCD gets a contiguous run of ids, decoded
+  // k'-tile fastest, so the workgroups running together on an XCD stream the SAME dY rows (same n-tile, same pixel
+  // range) and the same X rows (other taps / channel tiles of them) - the L2 serves most of both operands.
   int bid = blockIdx.x;
-  const int split = bid % p.splits;
-  bid /= p.splits;
+  {
+    const int nblk = p.tiles_n * p.tiles_k * p.splits;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const int tk = bid % p.tiles_k;
-  const int tn = bid / p.tiles_k;
+  bid /= p.tiles_k;
+  const int split = bid % p.splits;
+  const int tn = bid / p.splits;
   const int n0 = tn * T2_BN, k0 = tk * T2_BK;
   const int m_begin = split * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
