@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include "diffusion_amd.h"
 
+
 namespace {
 
 struct GemmNT2Params {
@@ -36,26 +37,37 @@ struct GemmNT2Params {
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
-constexpr int V2_BM = 256, V2_BK = 64;
-
-DEVINL int swz2(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// LDS image of a [rows x BK] bf16 tile: rows of BK*2 bytes, 16-B chunks XOR-swizzled so that the 16 lanes of a
+// ds_read_b128 quarter-wave (16 consecutive rows, same chunk) hit 16 distinct 16-B slots of the 256-B bank span
+template <int BK>
+DEVINL int swz_key(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+template <int BK>
+DEVINL int swz2(int row, int chunk) { return row * (BK * 2) + ((chunk ^ swz_key<BK>(row)) << 4); }
 
 DEVINL void glds16(const void* gsrc, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// MT x NT = 16x16 MFMA tiles per wave; WM x WN = wave grid (8 waves); BM = 16*MT*WM = 256, BN = 16*NT*WN
-template <int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
-  static_assert(WM * WN == 8 && 16 * MT * WM == V2_BM, "wave grid");
+// MT x NT = 16x16 MFMA tiles per wave; WM x WN = wave grid; BM = 16*MT*WM, BN = 16*NT*WN; BK = K-step (64 | 32).
+// 8 waves x BK 64: one workgroup per CU (the long-K workhorse).  4 waves x BK 32: 56 KiB of LDS, two workgroups per CU,
+// so that with only a few K-steps per tile (1x1 convs / linears with K <= 640) one workgroup's prologue and store
+// epilogue overlap the other's MFMAs.
+template <int MT, int NT, int WM, int WN, int BK>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt2_kernel(GemmNT2Params p) {
+  constexpr int NW = WM * WN;
+  constexpr int V2_BM = 16 * MT * WM, V2_BK = BK;
+  static_assert((NW == 8 || NW == 4) && (BK == 64 || BK == 32), "wave grid");
   constexpr int BN = 16 * NT * WN;
-  constexpr int BJ = (BN / 8 + 7) / 8;  // B row groups per wave
-  constexpr int A_BYTES = V2_BM * V2_BK * 2;  // 32 KiB
-  constexpr int B_BYTES = BN * V2_BK * 2;     // 16 / 20 KiB
+  constexpr int RG = 512 / BK;                // tile rows per 1-KiB DMA group (8 | 16)
+  constexpr int LR = BK / 8;                  // lanes (16-B chunks) per row
+  constexpr int AJ = V2_BM / RG / NW;         // A row groups per wave
+  constexpr int BGROUPS = BN / RG;            // 1-KiB row groups of the B tile
+  constexpr int BJ = (BGROUPS + NW - 1) / NW; // B row groups per wave
+  constexpr int A_BYTES = V2_BM * V2_BK * 2;
+  constexpr int B_BYTES = BN * V2_BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int BGROUPS = BN / 8;             // 1-KiB row groups of the B tile
-  constexpr int EPI_LD = 16 * NT + 4;
+  static_assert(V2_BM % (RG * NW) == 0, "A groups");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -77,14 +89,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
   const int gmul = (p.mode == 1) ? 2 : 1, gshift = (p.mode >= 2) ? 1 : 0, pmask = (p.mode == 2) ? 1 : 0;
   const int hlim = (p.mode >= 2) ? 2 * p.Hin : p.Hin, wlim = (p.mode >= 2) ? 2 * p.Win : p.Win;
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  // bias for this column block -> LDS (behind the stage buffers), read back in the epilogue; zeros when absent
+  if (tid < BN / 4) {
+    const int n = n0 + tid * 4;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    *reinterpret_cast<f32x4*>(smem + 2 * STAGE + tid * 16) = bv;
+  }
 
   // ---- per-lane DMA sources.  A: this wave fills row groups wave*4 .. wave*4+3 (8 rows each).
-  const int lrow = lane >> 3;
-  int pixbase[4], oh[4], ow[4], achunk[4];
-  bool mval[4];
+  const int lrow = lane / LR, lchunk = lane % LR;
+  int pixbase[AJ], oh[AJ], ow[AJ], achunk[AJ];
+  bool mval[AJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = wave * 32 + j * 8 + lrow;
+  for (int j = 0; j < AJ; ++j) {
+    const int row = (wave * AJ + j) * RG + lrow;
     const int m = m0 + row;
     mval[j] = m < p.M;
     const int mm = mval[j] ? m : 0;
@@ -93,18 +112,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
     oh[j] = rem / p.Wout;
     ow[j] = rem - oh[j] * p.Wout;
     pixbase[j] = b * p.Hin * p.Win;
-    achunk[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    achunk[j] = (lchunk ^ swz_key<BK>(row)) * 8;
   }
   // B: row groups wave, wave+8, ... (< BGROUPS)
   const bf16* wsrc[BJ];
   bool wval[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
-    const int g = wave + 8 * j;
-    const int row = g * 8 + lrow;
+    const int g = wave + NW * j;
+    const int row = g * RG + lrow;
     const int n = n0 + row;
     wval[j] = (g < BGROUPS) && (n < p.N);
-    wsrc[j] = p.W + (long)(wval[j] ? n : 0) * p.K + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    wsrc[j] = p.W + (long)(wval[j] ? n : 0) * p.K + (lchunk ^ swz_key<BK>(row)) * 8;
   }
 
   const int kstep_begin = split * p.ksteps_per_split;
@@ -122,18 +141,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
       s = tap - 3 * r;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < AJ; ++j) {
       // branch-free tap geometry (modes: 0 stride 1, 1 stride 2, 2 dgrad of stride 2, 3 fused nearest-2x upsample)
       const int th = oh[j] * gmul + r - pad, tw = ow[j] * gmul + s - pad;
       const bool ok = mval[j] && (unsigned)th < (unsigned)hlim && (unsigned)tw < (unsigned)wlim && !((th | tw) & pmask);
       const int ih = th >> gshift, iw = tw >> gshift;
       const void* src = ok ? (const void*)(p.A + (long)(pixbase[j] + ih * p.Win + iw) * p.lda + c0 + achunk[j])
                            : (const void*)zero;
-      glds16(src, Ab + (wave * 4 + j) * 1024);
+      glds16(src, Ab + (wave * AJ + j) * 1024);
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      const int g = wave + 8 * j;
+      const int g = wave + NW * j;
       if (g < BGROUPS) {
         const void* src = wval[j] ? (const void*)(wsrc[j] + k0) : (const void*)zero;
         glds16(src, Bb + g * 1024);
@@ -160,10 +179,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
     const int chunk = s * 4 + (lane >> 4);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
-      a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2(wm * (16 * MT) + i * 16 + (lane & 15), chunk));
+      a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2<BK>(wm * (16 * MT) + i * 16 + (lane & 15), chunk));
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      b[j] = *reinterpret_cast<const bf16x8*>(Bb + swz2(wn * (16 * NT) + j * 16 + (lane & 15), chunk));
+      b[j] = *reinterpret_cast<const bf16x8*>(Bb + swz2<BK>(wn * (16 * NT) + j * 16 + (lane & 15), chunk));
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -176,79 +195,111 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(GemmNT2Params p) {
   for (int t = 0; t < nk; ++t) {
     // the address arithmetic + DMA issue of step t+1 sits BETWEEN the two MFMA halves of step t: every wave leaves
     // the barrier at the same time, so issuing first would idle the matrix pipe of all four SIMDs during it
-    compute_half(t & 1, 0);
-    if (t + 1 < nk) issue((t + 1) & 1);
-    compute_half(t & 1, 1);
+    if constexpr (BK == 64) {
+      compute_half(t & 1, 0);
+      if (t + 1 < nk) issue((t + 1) & 1);
+      compute_half(t & 1, 1);
+    } else {  // one 32-deep MFMA pass per step; the co-resident workgroup covers the issue slot
+      if (t + 1 < nk) issue((t + 1) & 1);
+      compute_half(t & 1, 0);
+    }
     __syncthreads();  // vmcnt(0): step t+1 has landed; barrier: everyone is done reading stage t
   }
 
-  // ---- epilogue: one 16-row MFMA tile row at a time through a per-wave fp32 LDS strip
-  float* ew = reinterpret_cast<float*>(smem) + wave * (16 * EPI_LD);
-  constexpr int TASKS = 16 * 2 * NT;  // (row, 8-column chunk) pairs per strip
+  // ---- epilogue: the WN waves that share a row block stage their i-th 16-row MFMA strip side by side in LDS, then
+  // leave it as full BN-wide rows (640 B contiguous per row at BN 320) - per-wave strips would store and read the
+  // residual in 16*NT*2-byte pieces (160 B, straddling 128-B lines), which measured ~2.4 TB/s on the K=320 linears
+  constexpr int EPI_LD = BN + 4;
+  constexpr int STRIP = 16 * EPI_LD;                      // floats per 16-row strip
+  constexpr bool EPI_DB = 2 * WM * STRIP * 4 <= 2 * STAGE;  // double-buffered strips: one barrier per strip
+  constexpr int CH = BN / 8;                              // 8-column chunks per row
+  constexpr int TASKS = 16 * CH;                          // (row, chunk) pairs per strip, shared by 64*WN lanes
+  constexpr int PASSES = (TASKS + 64 * WN - 1) / (64 * WN);
+  // residual rows are fetched RD strips ahead (the MFMA operand registers are dead by now): with a load -> wait ->
+  // store chain per strip the epilogue exposed one HBM latency per strip, ~37 us per 256x320 tile on the K=320 linears
+  constexpr int RD = (MT < 10 / PASSES) ? MT : (10 / PASSES < 1 ? 1 : 10 / PASSES);
+  int trow[PASSES], tcol[PASSES];
+  bool tval[PASSES];
+#pragma unroll
+  for (int pss = 0; pss < PASSES; ++pss) {
+    const int task = wn * 64 + lane + 64 * WN * pss;
+    trow[pss] = task / CH;
+    tcol[pss] = (task - trow[pss] * CH) * 8;
+    tval[pss] = task < TASKS && n0 + tcol[pss] < p.N;
+  }
+  const int mrow0 = m0 + wm * (16 * MT);
+  const bool has_r = p.R != nullptr && p.splits == 1;
+  bf16x8 rres[RD][PASSES];
+  auto fetch_r = [&](int i, int slot) {
+#pragma unroll
+    for (int pss = 0; pss < PASSES; ++pss) {
+      const int m = mrow0 + i * 16 + trow[pss];
+      if (tval[pss] && m < p.M) rres[slot][pss] = ld8(p.R + (long)m * p.ldr + n0 + tcol[pss]);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < RD; ++i) {
+#pragma unroll
+    for (int pss = 0; pss < PASSES; ++pss) rres[i][pss] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (has_r) fetch_r(i, i);
+  }
+  const float* bias_lds = reinterpret_cast<const float*>(smem + 2 * STAGE);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
+    float* ew = reinterpret_cast<float*>(smem) + ((EPI_DB ? (i & 1) * WM : 0) + wm) * STRIP;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ew[((lane >> 4) * 4 + e) * EPI_LD + j * 16 + (lane & 15)] = acc[i][j][e];
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int e = 0; e < 4; ++e)
+        ew[((lane >> 4) * 4 + e) * EPI_LD + wn * (16 * NT) + j * 16 + (lane & 15)] = acc[i][j][e];
+    __syncthreads();
 #pragma unroll
-    for (int pss = 0; pss < (TASKS + 63) / 64; ++pss) {
-      const int task = lane + 64 * pss;
-      if (task < TASKS) {
-        const int row = task / (2 * NT);
-        const int col8 = (task - row * (2 * NT)) * 8;
-        const int m = m0 + wm * (16 * MT) + i * 16 + row;
-        const int n = n0 + wn * (16 * NT) + col8;
-        if (m < p.M && n < p.N) {
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8]);
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8 + 4]);
-          if (p.splits > 1) {  // split-K partial: raw fp32 sums into this split's slab; finalize kernel does the epilogue
-            float* cp = reinterpret_cast<float*>(p.C) + split * p.slab_stride + (long)m * p.N + n;
-            *reinterpret_cast<f32x4*>(cp) = v0;
-            *reinterpret_cast<f32x4*>(cp + 4) = v1;
-            continue;
-          }
-          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          if (p.bias) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+    for (int pss = 0; pss < PASSES; ++pss) {
+      const int row = trow[pss], col8 = tcol[pss];
+      const int m = mrow0 + i * 16 + row;
+      const int n = n0 + col8;
+      if (tval[pss] && m < p.M) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8]);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8 + 4]);
+        if (p.splits > 1) {  // split-K partial: raw fp32 sums into this split's slab; finalize kernel does the epilogue
+          float* cp = reinterpret_cast<float*>(p.C) + split * p.slab_stride + (long)m * p.N + n;
+          *reinterpret_cast<f32x4*>(cp) = v0;
+          *reinterpret_cast<f32x4*>(cp + 4) = v1;
+          continue;
+        }
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_lds + col8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_lds + col8 + 4);
+        float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] = v[e] * p.alpha + b0[e];
-              v[e + 4] = v[e + 4] * p.alpha + b1[e];
-            }
-          } else {
+        for (int e = 0; e < 4; ++e) {
+          v[e] = v0[e] * p.alpha + b0[e];
+          v[e + 4] = v1[e] * p.alpha + b1[e];
+        }
+        if (p.rowbias) {
+          const int b = m / HWo;
+          const bf16x8 rbv = ld8(p.rowbias + (long)b * p.ldrb + n);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-          }
-          if (p.rowbias) {
-            const int b = m / HWo;
-            const bf16x8 rbv = ld8(p.rowbias + (long)b * p.ldrb + n);
+          for (int e = 0; e < 8; ++e) v[e] += bf2f(rbv[e]);
+        }
+        if (has_r) {
+          const bf16x8 rv = rres[i % RD][pss];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bf2f(rbv[e]);
-          }
-          if (p.R) {
-            const bf16x8 rv = ld8(p.R + (long)m * p.ldr + n);
+          for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
+        }
+        if (p.out_fp32) {
+          float* cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+          *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
-          }
-          if (p.out_fp32) {
-            float* cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
-            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
-          } else {
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-            st8(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, o);
-          }
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+          st8(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, o);
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (has_r && i + RD < MT) fetch_r(i + RD, i % RD);
+    if (!EPI_DB) __syncthreads();  // single strip buffer: everyone is done reading before it is rewritten
   }
 }
 
@@ -295,16 +346,18 @@ __global__ void splitk_finalize_kernel(GemmNT2Params p, const float* ws) {
   }
 }
 
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT, int WM, int WN, int BK>
 int launch_v2(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream) {
   GemmNT2Params p = p0;
+  constexpr int V2_BM = 16 * MT * WM, V2_BK = BK, NTHREADS = 64 * WM * WN;
   constexpr int BN = 16 * NT * WN;
-  constexpr int SMEM = 2 * (V2_BM * V2_BK * 2 + BN * V2_BK * 2);
+  constexpr int SMEM = 2 * (V2_BM * V2_BK * 2 + BN * V2_BK * 2) + BN * 4;  // 2 stages + bias
+  static_assert(SMEM - BN * 4 >= WM * 16 * (BN + 4) * 4, "epilogue strips fit in the stage buffers");
   p.tiles_m = (p.M + V2_BM - 1) / V2_BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<MT, NT, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
+    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<MT, NT, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
         hipSuccess)
       return DA_ERR_LAUNCH;
     attr_set = true;
@@ -317,7 +370,7 @@ int launch_v2(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream
   if (p.splits > 1) {
     GemmNT2Params pk = p;
     pk.C = ws;  // partial slabs
-    hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(512), SMEM,
+    hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(NTHREADS), SMEM,
                        stream, pk);
     DA_CHECK_LAUNCH();
     const long total = (long)p.M * (p.N >> 3);
@@ -327,7 +380,7 @@ int launch_v2(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream
     DA_CHECK_LAUNCH();
     return DA_OK;
   }
-  hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(512), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK>), dim3(p.tiles_m * p.tiles_n), dim3(NTHREADS), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -348,6 +401,7 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
   p.ksize = ksize; p.mode = mode; p.out_fp32 = out_fp32; p.alpha = alpha;
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
-  if (variant == 10) return launch_v2<8, 5, 2, 4>(p, splits, ws, stream);
-  return variant == 5 ? launch_v2<4, 5, 4, 2>(p, splits, ws, stream) : launch_v2<4, 4, 4, 2>(p, splits, ws, stream);
+  if (variant == 10) return launch_v2<8, 5, 2, 4, 64>(p, splits, ws, stream);
+  if (variant == 11) return launch_v2<4, 10, 2, 2, 32>(p, 1, ws, stream);  // 128 x 320 x 32, 4 waves, 2 workgroups / CU
+  return variant == 5 ? launch_v2<4, 5, 4, 2, 64>(p, splits, ws, stream) : launch_v2<4, 4, 4, 2, 64>(p, splits, ws, stream);
 }
