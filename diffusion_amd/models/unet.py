@@ -385,7 +385,7 @@ class UNetHIP(nn.Module):
                     continue
                 N, T, C = st.ntc
                 recs.append(struct.pack('<qqiiii', st.off, st.toff, N, T, C, first))
-                first += T * ((N + 31) // 32) * ((C + 31) // 32)
+                first += T * ((N + 63) // 64) * ((C + 63) // 64)
             self._tdesc = torch.frombuffer(bytearray(b''.join(recs)), dtype=torch.uint8).to(self.device_)
             self._tdesc_n, self._tdesc_blocks = len(recs), first
         ops.transpose_weights_batched(self.shadow, self.shadow_t, self._tdesc, self._tdesc_n, self._tdesc_blocks)

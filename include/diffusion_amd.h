@@ -144,7 +144,7 @@ int da_transpose_weight(const void* src, void* dst, int N, int T, int C, da_stre
 
 /* the same for many tensors in one launch.  desc: device array of ntensors records
  * {long src_off, long dst_off (elements from the bases), int N, int T, int C, int first_block}; tensor i owns blocks
- * [first_block_i, first_block_i + T*ceil(N/32)*ceil(C/32)); total_blocks = their sum. */
+ * [first_block_i, first_block_i + T*ceil(N/64)*ceil(C/64)); total_blocks = their sum. */
 int da_transpose_weights_batched(const void* src_base, void* dst_base, const void* desc, int ntensors, int total_blocks,
                                  da_stream_t stream);
 
