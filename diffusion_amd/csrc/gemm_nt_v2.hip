@@ -53,7 +53,9 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
 // 8 waves x BK 64: one workgroup per CU (the long-K workhorse).  4 waves x BK 32: 56 KiB of LDS, two workgroups per CU,
 // so that with only a few K-steps per tile (1x1 convs / linears with K <= 640) one workgroup's prologue and store
 // epilogue overlap the other's MFMAs.
-template <int MT, int NT, int WM, int WN, int BK>
+// UPS: gather mode 3 (conv over a nearest-2x upsampled image) - a compile-time split so that the K loop of the other
+// modes stays one basic block.
+template <int MT, int NT, int WM, int WN, int BK, bool UPS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt2_kernel(GemmNT2Params p) {
   constexpr int NW = WM * WN;
   constexpr int V2_BM = 16 * MT * WM, V2_BK = BK;
@@ -97,33 +99,47 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt2_kernel(GemmNT2Params
     *reinterpret_cast<f32x4*>(smem + 2 * STAGE + tid * 16) = bv;
   }
 
-  // ---- per-lane DMA sources.  A: this wave fills row groups wave*4 .. wave*4+3 (8 rows each).
+  // ---- per-lane DMA sources, reduced ONCE per tile to what a K-step needs: the address arithmetic of a step runs on
+  // every wave with the matrix pipe idle (it measured ~0.45 us of a ~2.2 us step when done from scratch each time).
+  // A row j of this lane (row groups wave*AJ .. wave*AJ+AJ-1):
+  //   abase[j]  pointer to the row's tap-(0,0) source pixel (+ this lane's swizzled 16-B chunk)
+  //   amask[j]  bit t: tap t reads inside the image (modes: 0 stride 1, 1 stride 2, 2 dgrad of stride 2, 3 fused
+  //             nearest-2x upsample); bits 16/17: parity of the output row / column (mode 3 only)
+  // so that a step adds one wave-uniform offset (tap displacement + channel offset) and selects the zero page.
   const int lrow = lane / LR, lchunk = lane % LR;
-  int pixbase[AJ], oh[AJ], ow[AJ], achunk[AJ];
-  bool mval[AJ];
+  const int ntaps = p.ksize * p.ksize;
+  const bf16* abase[AJ];
+  unsigned amask[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int row = (wave * AJ + j) * RG + lrow;
     const int m = m0 + row;
-    mval[j] = m < p.M;
-    const int mm = mval[j] ? m : 0;
+    const bool mval = m < p.M;
+    const int mm = mval ? m : 0;
     const int b = mm / HWo;
     const int rem = mm - b * HWo;
-    oh[j] = rem / p.Wout;
-    ow[j] = rem - oh[j] * p.Wout;
-    pixbase[j] = b * p.Hin * p.Win;
-    achunk[j] = (lchunk ^ swz_key<BK>(row)) * 8;
+    const int oh = rem / p.Wout;
+    const int ow = rem - oh * p.Wout;
+    unsigned mask = ((oh & 1) << 16) | ((ow & 1) << 17);
+    for (int t = 0; t < ntaps; ++t) {
+      const int r = p.ksize == 3 ? t / 3 : 0, s2 = p.ksize == 3 ? t - 3 * r : 0;
+      const int th = oh * gmul + r - pad, tw = ow * gmul + s2 - pad;
+      const bool ok = mval && (unsigned)th < (unsigned)hlim && (unsigned)tw < (unsigned)wlim && !((th | tw) & pmask);
+      mask |= (ok ? 1u : 0u) << t;
+    }
+    amask[j] = mask;
+    const int bh = (oh * gmul - pad) >> gshift, bw = (ow * gmul - pad) >> gshift;
+    abase[j] = p.A + ((long)(b * p.Hin * p.Win) + (long)bh * p.Win + bw) * p.lda + (lchunk ^ swz_key<BK>(row)) * 8;
   }
-  // B: row groups wave, wave+8, ... (< BGROUPS)
-  const bf16* wsrc[BJ];
-  bool wval[BJ];
+  // B: row groups wave, wave+NW, ... (< BGROUPS): uniform base W + k0 plus a constant per-lane element offset.
+  // Rows past N are clamped (their products land in columns the epilogue never stores).
+  unsigned woff[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     const int g = wave + NW * j;
     const int row = g * RG + lrow;
-    const int n = n0 + row;
-    wval[j] = (g < BGROUPS) && (n < p.N);
-    wsrc[j] = p.W + (long)(wval[j] ? n : 0) * p.K + (lchunk ^ swz_key<BK>(row)) * 8;
+    const int n = min(n0 + row, p.N - 1);
+    woff[j] = (unsigned)n * (unsigned)p.K + (lchunk ^ swz_key<BK>(row)) * 8;
   }
 
   const int kstep_begin = split * p.ksteps_per_split;
@@ -132,38 +148,43 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt2_kernel(GemmNT2Params
   int k0 = kstep_begin * V2_BK;
   int tap = k0 / p.Cin;
   int c0 = k0 - tap * p.Cin;
-  auto issue = [&](int stage) {
+  // live == false (the step after the last): A reads the zero page, B re-reads K-step 0 - no branch in the K loop
+  auto issue = [&](int stage, bool live) {
     char* Ab = smem + stage * STAGE;
     char* Bb = Ab + A_BYTES;
-    int r = 0, s = 0;
-    if (p.ksize == 3) {
-      r = tap / 3;
-      s = tap - 3 * r;
-    }
+    const int r = tap / 3, s2 = tap - 3 * r;  // ksize 1: tap stays 0
+    const unsigned tapbit = live ? (1u << tap) : 0u;
+    if constexpr (!UPS) {
+      // tap displacement in source pixels: r, s (stride 1 / 2) or (r+pad)/2 (dgrad of stride 2, only even taps valid)
+      const int dr = (r + (gshift ? pad : 0)) >> gshift, ds = (s2 + (gshift ? pad : 0)) >> gshift;
+      const long soff = (long)(dr * p.Win + ds) * p.lda + c0;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      // branch-free tap geometry (modes: 0 stride 1, 1 stride 2, 2 dgrad of stride 2, 3 fused nearest-2x upsample)
-      const int th = oh[j] * gmul + r - pad, tw = ow[j] * gmul + s - pad;
-      const bool ok = mval[j] && (unsigned)th < (unsigned)hlim && (unsigned)tw < (unsigned)wlim && !((th | tw) & pmask);
-      const int ih = th >> gshift, iw = tw >> gshift;
-      const void* src = ok ? (const void*)(p.A + (long)(pixbase[j] + ih * p.Win + iw) * p.lda + c0 + achunk[j])
-                           : (const void*)zero;
-      glds16(src, Ab + (wave * AJ + j) * 1024);
+      for (int j = 0; j < AJ; ++j) {
+        const void* src = (amask[j] & tapbit) ? (const void*)(abase[j] + soff) : (const void*)zero;
+        glds16(src, Ab + (wave * AJ + j) * 1024);
+      }
+    } else {
+      // nearest-2x upsample: source row of tap r is (oh + r - pad) >> 1, which depends on the parity of oh
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int ph = (amask[j] >> 16) & 1, pw = (amask[j] >> 17) & 1;
+        const int dr = (r + pad * (1 - ph)) >> 1, ds = (s2 + pad * (1 - pw)) >> 1;
+        const long soff = (long)(dr * p.Win + ds) * p.lda + c0;
+        const void* src = (amask[j] & tapbit) ? (const void*)(abase[j] + soff) : (const void*)zero;
+        glds16(src, Ab + (wave * AJ + j) * 1024);
+      }
     }
+    const bf16* wb = p.W + (live ? k0 : 0);
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       const int g = wave + NW * j;
-      if (g < BGROUPS) {
-        const void* src = wval[j] ? (const void*)(wsrc[j] + k0) : (const void*)zero;
-        glds16(src, Bb + g * 1024);
-      }
+      if (BGROUPS % NW == 0 || g < BGROUPS) glds16(wb + woff[j], Bb + g * 1024);
     }
     k0 += V2_BK;
     c0 += V2_BK;
-    if (c0 >= p.Cin) {
-      c0 = 0;
-      ++tap;
-    }
+    const bool wrap = c0 >= p.Cin;
+    c0 = wrap ? 0 : c0;
+    tap += wrap ? 1 : 0;
   };
 
   f32x4 acc[MT][NT];
@@ -190,17 +211,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt2_kernel(GemmNT2Params
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   };
 
-  issue(0);
+  issue(0, true);
   __syncthreads();
   for (int t = 0; t < nk; ++t) {
     // the address arithmetic + DMA issue of step t+1 sits BETWEEN the two MFMA halves of step t: every wave leaves
     // the barrier at the same time, so issuing first would idle the matrix pipe of all four SIMDs during it
     if constexpr (BK == 64) {
       compute_half(t & 1, 0);
-      if (t + 1 < nk) issue((t + 1) & 1);
+      issue((t + 1) & 1, t + 1 < nk);
       compute_half(t & 1, 1);
     } else {  // one 32-deep MFMA pass per step; the co-resident workgroup covers the issue slot
-      if (t + 1 < nk) issue((t + 1) & 1);
+      issue((t + 1) & 1, t + 1 < nk);
       compute_half(t & 1, 0);
     }
     __syncthreads();  // vmcnt(0): step t+1 has landed; barrier: everyone is done reading stage t
@@ -346,8 +367,8 @@ __global__ void splitk_finalize_kernel(GemmNT2Params p, const float* ws) {
   }
 }
 
-template <int MT, int NT, int WM, int WN, int BK>
-int launch_v2(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream) {
+template <int MT, int NT, int WM, int WN, int BK, bool UPS>
+int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream) {
   GemmNT2Params p = p0;
   constexpr int V2_BM = 16 * MT * WM, V2_BK = BK, NTHREADS = 64 * WM * WN;
   constexpr int BN = 16 * NT * WN;
@@ -357,7 +378,7 @@ int launch_v2(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream
   p.tiles_n = (p.N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<MT, NT, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
+    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
         hipSuccess)
       return DA_ERR_LAUNCH;
     attr_set = true;
@@ -370,7 +391,7 @@ int launch_v2(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream
   if (p.splits > 1) {
     GemmNT2Params pk = p;
     pk.C = ws;  // partial slabs
-    hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(NTHREADS), SMEM,
+    hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(NTHREADS), SMEM,
                        stream, pk);
     DA_CHECK_LAUNCH();
     const long total = (long)p.M * (p.N >> 3);
@@ -380,9 +401,15 @@ int launch_v2(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream
     DA_CHECK_LAUNCH();
     return DA_OK;
   }
-  hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK>), dim3(p.tiles_m * p.tiles_n), dim3(NTHREADS), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS>), dim3(p.tiles_m * p.tiles_n), dim3(NTHREADS), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
+}
+
+template <int MT, int NT, int WM, int WN, int BK>
+int launch_v2(const GemmNT2Params& p, int splits, float* ws, hipStream_t stream) {
+  return p.mode == 3 ? launch_v2_mode<MT, NT, WM, WN, BK, true>(p, splits, ws, stream)
+                     : launch_v2_mode<MT, NT, WM, WN, BK, false>(p, splits, ws, stream);
 }
 
 }  // namespace
