@@ -26,6 +26,7 @@ struct GemmTN2Params {
   int Hin, Win, Hout, Wout, ksize, mode;
   FastDiv div_hw, div_w, div_cin;
   int tiles_n, tiles_k, splits, m_per_split;
+  int period;  // FAST path: the border pattern of a lane's X rows repeats every `period` 64-pixel steps
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page_tn[256];
@@ -47,7 +48,14 @@ DEVINL void glds16_tn(const void* gsrc, char* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int T2_BK>  // output tile columns (k'): 192 (256 also fits the swizzle scheme but spills registers)
+// T2_BK: output tile columns (k'): 192 (256 also fits the swizzle scheme but spills registers).
+// FAST: stride-1 gather (mode 0) with M % 64 == 0 and a border pattern that repeats every p.period <= 64 steps
+// (HW % 64 == 0, or 64 % HW == 0 with period 1) - every stride-1 3x3 conv and every linear layer of the U-Net.  There the
+// source pixel of a lane slot is LINEAR in the step (pixel + tap displacement), so the K loop needs no coordinate
+// arithmetic: dY loads are uniform base + a constant lane offset, X loads add one select on a precomputed validity
+// mask.  The generic path (strided / upsampled gathers, ragged M) recomputes coordinates each step: ~105 VALU
+// instructions per step that run on every wave with the matrix pipe idle.
+template <int T2_BK, bool FAST>
 __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   constexpr int T2_SB = T2_BK * 2;
   constexpr int T2_B_BYTES = T2_MS * T2_SB;
@@ -85,6 +93,71 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   const int gmul = (p.mode == 1) ? 2 : 1, gshift = (p.mode == 3) ? 1 : 0;
   const int hlim = (p.mode == 3) ? p.Hout : p.Hin, wlim = (p.mode == 3) ? p.Wout : p.Win;
   const char* zero = reinterpret_cast<const char*>(g_zero_page_tn);
+
+  int mcur_f = m_begin;
+  // ---- FAST-path descriptors (see the template comment); the generic ones follow
+  unsigned fa_off[T2_AJ], fx_off[T2_BJ], fx_m0[T2_BJ], fx_m1[T2_BJ];
+  if constexpr (FAST) {
+#pragma unroll
+    for (int j = 0; j < T2_AJ; ++j) {
+      const int ci = (wave * T2_AJ + j) * 64 + lane;
+      const int row = ci / 40, pc = ci - row * 40;
+      const int lc = pc ^ swA(row);
+      const int n = min(n0 + lc * 8, p.N - 8);  // columns past N: clamped (their outputs are never stored)
+      fa_off[j] = (unsigned)(row * (int)p.lddy + n);
+    }
+#pragma unroll
+    for (int j = 0; j < T2_BJ; ++j) {
+      const int ci = (wave * T2_BJ + j) * 64 + lane;
+      const int row = ci / C16B, pc = ci - row * C16B;
+      const int lc = pc ^ swB<T2_BK>(row);
+      const int kk = k0 + lc * 8;
+      const bool kok = kk < p.Kt;
+      const unsigned tap = kok ? fdiv((unsigned)kk, p.div_cin) : 0u;
+      const int c = kok ? kk - (int)tap * p.Cin : 0;
+      const int r = (int)tap / 3, s2 = (int)tap - 3 * r;  // ksize 1: tap == 0
+      // element offset from X + (pixel_of_step - pad*(Win+1)) * ldx : never negative
+      fx_off[j] = (unsigned)((row + r * p.Win + s2) * (int)p.ldx + c);
+      unsigned m0 = 0, m1 = 0;
+      if (kok) {
+        if (p.ksize == 1) {
+          m0 = m1 = 0xffffffffu;
+        } else {
+          for (int ph = 0; ph < p.period; ++ph) {
+            const unsigned mm = (unsigned)(m_begin + row + T2_MS * ph);
+            const unsigned rem = mm - fdiv(mm, p.div_hw) * (unsigned)HWo;
+            const int oh = (int)fdiv(rem, p.div_w);
+            const int ow = (int)rem - oh * p.Wout;
+            const bool ok = (unsigned)(oh + r - 1) < (unsigned)p.Hin && (unsigned)(ow + s2 - 1) < (unsigned)p.Win;
+            if (ph < 32) m0 |= (ok ? 1u : 0u) << ph;
+            else m1 |= (ok ? 1u : 0u) << (ph - 32);
+          }
+        }
+      }
+      fx_m0[j] = m0;
+      fx_m1[j] = m1;
+    }
+  }
+  int phase = 0;
+  auto issue_fast = [&](int stage, bool live) {
+    char* Ab = smem + stage * T2_STAGE;
+    char* Bb = Ab + T2_A_BYTES;
+    const int mc = live ? mcur_f : m_begin;  // the step after the last re-reads step 0 (X rows masked off)
+    const bf16* ab = p.dY + (long)mc * p.lddy;
+#pragma unroll
+    for (int j = 0; j < T2_AJ; ++j) glds16_tn(ab + fa_off[j], Ab + (wave * T2_AJ + j) * 1024);
+    const bf16* xb = p.X + ((long)mc - pad * (p.Win + 1)) * p.ldx;
+    const unsigned pb0 = (live && phase < 32) ? (1u << phase) : 0u;
+    const unsigned pb1 = (live && phase >= 32) ? (1u << (phase - 32)) : 0u;
+#pragma unroll
+    for (int j = 0; j < T2_BJ; ++j) {
+      const bool ok = ((fx_m0[j] & pb0) | (fx_m1[j] & pb1)) != 0;
+      const void* src = ok ? (const void*)(xb + fx_off[j]) : (const void*)zero;
+      glds16_tn(src, Bb + (wave * T2_BJ + j) * 1024);
+    }
+    mcur_f += T2_MS;
+    phase = (phase + 1 == p.period) ? 0 : phase + 1;
+  };
 
   // ---- DMA source descriptors (fixed per lane and instruction slot for the whole kernel)
   // dY image: chunk ci = (wave*AJ + j)*64 + lane ; row = ci / 40 ; physical chunk pc = ci % 40 ; logical lc = pc ^ swA(row)
@@ -224,15 +297,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     }
   };
 
-  issue(0);
-  __syncthreads();
-  for (int t = 0; t < nsteps; ++t) {
-    // DMA issue of the next stage between the two MFMA halves (all waves leave the barrier together: issuing first
-    // would idle every SIMD's matrix pipe during the address arithmetic)
-    compute_half(t & 1, 0);
-    if (t + 1 < nsteps) issue((t + 1) & 1);
-    compute_half(t & 1, 1);
+  // DMA issue of the next stage between the two MFMA halves (all waves leave the barrier together: issuing first
+  // would idle every SIMD's matrix pipe during the address arithmetic)
+  if constexpr (FAST) {
+    issue_fast(0, true);
     __syncthreads();
+    for (int t = 0; t < nsteps; ++t) {  // one basic block: no branch around the issue
+      compute_half(t & 1, 0);
+      issue_fast((t + 1) & 1, t + 1 < nsteps);
+      compute_half(t & 1, 1);
+      __syncthreads();
+    }
+  } else {
+    issue(0);
+    __syncthreads();
+    for (int t = 0; t < nsteps; ++t) {
+      compute_half(t & 1, 0);
+      if (t + 1 < nsteps) issue((t + 1) & 1);
+      compute_half(t & 1, 1);
+      __syncthreads();
+    }
   }
 
 #pragma unroll
@@ -261,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   }
 }
 
-template <int BK>
+template <int BK, bool FAST>
 int launch_tn2(GemmTN2Params p, hipStream_t stream) {
   constexpr int SMEM = 2 * (T2_A_BYTES + T2_MS * BK * 2);
   p.tiles_n = (p.N + T2_BN - 1) / T2_BN;
@@ -302,12 +386,12 @@ int launch_tn2(GemmTN2Params p, hipStream_t stream) {
   p.m_per_split = mps;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_tn2_kernel<BK>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
+    if (hipFuncSetAttribute((const void*)gemm_tn2_kernel<BK, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
         hipSuccess)
       return DA_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_tn2_kernel<BK>, dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST>), dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -327,5 +411,11 @@ int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X
   p.div_cin = make_fastdiv((unsigned)Cin);
   p.tiles_n = p.tiles_k = p.splits = p.m_per_split = 0;
   (void)variant;  // the 320x256 instantiation (160 accumulators) spills on gfx950 and lost to 320x192 everywhere
-  return launch_tn2<192>(p, stream);
+  const int HWo = Hout * Wout;
+  p.period = 0;
+  if (mode == 0 && M % T2_MS == 0 && N >= 8) {
+    if (HWo % T2_MS == 0 && HWo / T2_MS <= 64) p.period = HWo / T2_MS;
+    else if (T2_MS % HWo == 0) p.period = 1;
+  }
+  return p.period ? launch_tn2<192, true>(p, stream) : launch_tn2<192, false>(p, stream);
 }
