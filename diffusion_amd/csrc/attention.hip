@@ -14,6 +14,8 @@
 //   of fp32 atomics, which keeps all three gradients bitwise reproducible.
 // Row-read operands (K, V, Q, dO by rows) use a 128-B-row image with the 16-B chunk XOR ((row>>1)&7).
 // Softmax is computed in the exp2 domain: p = exp2(s*scale*log2e - L2), L2 = m + log2(sum) saved per row.
+#include <type_traits>
+
 #include "common.hpp"
 #include "diffusion_amd.h"
 
@@ -53,6 +55,19 @@ DEVINL bf16x8 pack8(const f32x16& x, int s) {
   return r;
 }
 
+// The softmax arithmetic runs on register PAIRS: these kernels are bound by VALU issue slots (PMC: 8-17 VALU
+// instructions per 32-cycle MFMA, matrix pipe ~25 % busy), and v_pk_fma/add/mul_f32 handle two fp32 per slot.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEVINL f32x2 pair(const f32x16& v, int i) { return f32x2{v[2 * i], v[2 * i + 1]}; }
+DEVINL void set_pair(f32x16& v, int i, f32x2 x) { v[2 * i] = x.x; v[2 * i + 1] = x.y; }
+DEVINL f32x2 exp2_2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+
+DEVINL float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 DEVINL int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ------------------------------------------------------------------------------------------------
@@ -84,15 +99,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int nt = (p.Nk + 63) / 64;
   const int lrow = tid >> 3, lchunk = tid & 7;
   bf16x8 rk[2], rv[2];
+  // this thread's K / V source rows of tile 0; advanced by 64 rows per load (no per-tile address products)
+  const bf16* kp = p.K + ((long)b * p.Nk + lrow) * p.ldk + hd * 64 + lchunk * 8;
+  const bf16* vp = p.V + ((long)b * p.Nk + lrow) * p.ldv + hd * 64 + lchunk * 8;
   auto load = [&](int t) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int key = t * 64 + lrow + 32 * i;
-      bool ok = key < p.Nk;
-      long base = ((long)b * p.Nk + key);
-      rk[i] = ok ? ld8(p.K + base * p.ldk + hd * 64 + lchunk * 8) : zero8();
-      rv[i] = ok ? ld8(p.V + base * p.ldv + hd * 64 + lchunk * 8) : zero8();
+      const bool ok = t * 64 + lrow + 32 * i < p.Nk;
+      rk[i] = ok ? ld8(kp + 32 * i * p.ldk) : zero8();
+      rv[i] = ok ? ld8(vp + 32 * i * p.ldv) : zero8();
     }
+    kp += 64 * p.ldk;
+    vp += 64 * p.ldv;
   };
   auto store = [&](int st) {
     char* Ks = smem + st * FW_STAGE;
@@ -108,7 +126,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   load(0);
   store(0);
   __syncthreads();
-  for (int t = 0; t < nt; ++t) {
+  // One 64-key step.  TAIL (the ragged last tile) is a compile-time split: written as a run-time `if`, the key masking
+  // was if-converted into every step (32 v_cmp + 32 v_cndmask + index adds, a third of the loop's VALU work).
+  auto step = [&](int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     if (t + 1 < nt) load(t + 1);
     const char* Ks = smem + (t & 1) * FW_STAGE;
     const char* Vs = Ks + 64 * 128;
@@ -122,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
     }
-    if (t * 64 + 64 > p.Nk) {  // ragged tail tile only
+    if constexpr (TAIL) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         int key = t * 64 + acc_row(i, lane);
@@ -132,25 +153,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
     float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+    for (int i = 1; i < 16; ++i) mx = max3(mx, s0[i], s1[i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (__any(mx > m)) {
       const float mn = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f((m - mn) * p.sc);
       l *= alpha;
+      const f32x2 al2 = {alpha, alpha};
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+      for (int i = 0; i < 8; ++i) {
+        set_pair(o0, i, pair(o0, i) * al2);
+        set_pair(o1, i, pair(o1, i) * al2);
+      }
       m = mn;
     }
     const float msc = -m * p.sc;
-    float ls = 0.f;
+    const f32x2 sc2 = {p.sc, p.sc}, msc2 = {msc, msc};
+    f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      s0[i] = __builtin_amdgcn_exp2f(fmaf(s0[i], p.sc, msc));
-      s1[i] = __builtin_amdgcn_exp2f(fmaf(s1[i], p.sc, msc));
-      ls += s0[i] + s1[i];
+    for (int i = 0; i < 8; ++i) {
+      const f32x2 e0 = exp2_2(__builtin_elementwise_fma(pair(s0, i), sc2, msc2));
+      const f32x2 e1 = exp2_2(__builtin_elementwise_fma(pair(s1, i), sc2, msc2));
+      set_pair(s0, i, e0);
+      set_pair(s1, i, e1);
+      ls2 += e0 + e1;
     }
-    l += ls;
+    l += ls2.x + ls2.y;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       bf16x8 pa = pack8(s0, s2), pb = pack8(s1, s2);
@@ -163,7 +191,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
     if (t + 1 < nt) store((t + 1) & 1);
     __syncthreads();
-  }
+  };
+  const int nfull = p.Nk / 64;
+  for (int t = 0; t < nfull; ++t) step(t, std::false_type{});
+  if (nfull < nt) step(nfull, std::true_type{});
   const float lt = l + __shfl_xor(l, 32, 64);
   const float inv = 1.0f / lt;
   if (qv) {
@@ -219,15 +250,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int nt = (p.Nk + 63) / 64;
   const int lrow = tid >> 3, lchunk = tid & 7;
   bf16x8 rk[2], rv[2];
+  const bf16* kp = p.K + ((long)b * p.Nk + lrow) * p.ldk + hd * 64 + lchunk * 8;
+  const bf16* vp = p.V + ((long)b * p.Nk + lrow) * p.ldv + hd * 64 + lchunk * 8;
   auto load = [&](int t) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int key = t * 64 + lrow + 32 * i;
-      bool ok = key < p.Nk;
-      long base = ((long)b * p.Nk + key);
-      rk[i] = ok ? ld8(p.K + base * p.ldk + hd * 64 + lchunk * 8) : zero8();
-      rv[i] = ok ? ld8(p.V + base * p.ldv + hd * 64 + lchunk * 8) : zero8();
+      const bool ok = t * 64 + lrow + 32 * i < p.Nk;
+      rk[i] = ok ? ld8(kp + 32 * i * p.ldk) : zero8();
+      rv[i] = ok ? ld8(vp + 32 * i * p.ldv) : zero8();
     }
+    kp += 64 * p.ldk;
+    vp += 64 * p.ldv;
   };
   auto store = [&](int st) {
     char* Ks = smem + st * DQ_STAGE;
@@ -245,16 +278,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   load(0);
   store(0);
   __syncthreads();
-  for (int t = 0; t < nt; ++t) {
+  auto step = [&](int t, auto tail_tag) {  // TAIL: compile-time split, see attn_fwd_kernel
+    constexpr bool TAIL = decltype(tail_tag)::value;
     if (t + 1 < nt) load(t + 1);
     const char* Ks = smem + (t & 1) * DQ_STAGE;
     const char* Vs = Ks + 64 * 128;
     const char* Kt = Ks + 2 * 64 * 128;
-    const bool tail = t * 64 + 64 > p.Nk;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int kb = half * 32;
-      if (t * 64 + kb >= p.Nk) break;
+      if (TAIL && t * 64 + kb >= p.Nk) break;
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -265,12 +298,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
       }
+      {
+        const f32x2 sc2 = {p.sc, p.sc}, nl2 = {nL2q, nL2q}, nde2 = {-delta, -delta};
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float pv = __builtin_amdgcn_exp2f(fmaf(s[i], p.sc, nL2q));
-        s[i] = pv * (dp[i] - delta);
+        for (int i = 0; i < 8; ++i) {
+          const f32x2 pv = exp2_2(__builtin_elementwise_fma(pair(s, i), sc2, nl2));
+          set_pair(s, i, pv * (pair(dp, i) + nde2));
+        }
       }
-      if (tail) {
+      if constexpr (TAIL) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           if (t * 64 + kb + acc_row(i, lane) >= p.Nk) s[i] = 0.f;
@@ -286,7 +322,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     }
     if (t + 1 < nt) store((t + 1) & 1);
     __syncthreads();
-  }
+  };
+  const int nfull = p.Nk / 64;
+  for (int t = 0; t < nfull; ++t) step(t, std::false_type{});
+  if (nfull < nt) step(nfull, std::true_type{});
   if (qv) {
     bf16* op = p.dQ + ((long)b * p.Nq + q) * p.lddq + hd * 64;
 #pragma unroll
@@ -332,19 +371,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const int lrow = tid >> 3, lchunk = tid & 7;  // 32 rows x 8 chunks = 256 threads
   bf16x8 rq, rdo;
   float rl = 0.f, rd = 0.f;
+  const bf16* qp = p.Q + ((long)b * p.Nq + lrow) * p.ldq + hd * 64 + lchunk * 8;
+  const bf16* dop = p.dO + ((long)b * p.Nq + lrow) * p.lddo + hd * 64 + lchunk * 8;
+  const float* l2p = p.L2 + ((long)b * p.H + hd) * p.Nq + tid;
+  const float* dlp = p.Delta + ((long)b * p.H + hd) * p.Nq + tid;
   auto load = [&](int t) {
-    int qq = t * 32 + lrow;
-    bool ok = qq < p.Nq;
-    long base = ((long)b * p.Nq + qq);
-    rq = ok ? ld8(p.Q + base * p.ldq + hd * 64 + lchunk * 8) : zero8();
-    rdo = ok ? ld8(p.dO + base * p.lddo + hd * 64 + lchunk * 8) : zero8();
+    const bool ok = t * 32 + lrow < p.Nq;
+    rq = ok ? ld8(qp) : zero8();
+    rdo = ok ? ld8(dop) : zero8();
     if (tid < 32) {
-      int q2 = t * 32 + tid;
-      bool ok2 = q2 < p.Nq;
-      long si = ((long)b * p.H + hd) * p.Nq + q2;
-      rl = ok2 ? -p.L2[si] : 0.f;
-      rd = ok2 ? p.Delta[si] : 0.f;
+      const bool ok2 = t * 32 + tid < p.Nq;
+      rl = ok2 ? -*l2p : 0.f;
+      rd = ok2 ? -*dlp : 0.f;  // negated: dS = P * (dP + (-delta)) is one packed add
     }
+    qp += 32 * p.ldq;
+    dop += 32 * p.lddo;
+    l2p += 32;
+    dlp += 32;
   };
   auto store = [&](int st) {
     char* Qs = smem + st * KV_STAGE;
@@ -388,12 +431,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     for (int rg = 0; rg < 4; ++rg) {
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + 8 * rg + 4 * h);
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + 8 * rg + 4 * h);
+      const f32x2 sc2 = {p.sc, p.sc};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = rg * 4 + e;
-        float pv = __builtin_amdgcn_exp2f(fmaf(s[i], p.sc, l4[e]));
-        pr[i] = pv;
-        s[i] = pv * (dp[i] - d4[e]);
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int i = rg * 2 + e2;  // pair index: accumulator registers 2i, 2i+1 = rows 2*e2, 2*e2+1 of this group
+        const f32x2 pv = exp2_2(__builtin_elementwise_fma(pair(s, i), sc2, f32x2{l4[2 * e2], l4[2 * e2 + 1]}));
+        set_pair(pr, i, pv);
+        set_pair(s, i, pv * (pair(dp, i) + f32x2{d4[2 * e2], d4[2 * e2 + 1]}));
       }
     }
     // rows beyond Nq in the last tile: Q = dO = 0, L2 = delta = 0 -> p = 1, dS = 0, and dO^T.P adds 0.
