@@ -169,12 +169,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNParams p) {
 
 // large-tile LDS-DMA variant (gemm_tn_v2.hip)
 int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias,
-                           int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, hipStream_t stream);
+                           int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, float* ws,
+                           long ws_floats, hipStream_t stream);
 int g_tn_variant = 0;  // 0 auto, 1 force v1 (128x128x32), 2 force v2 (320x192x64); da_set_option
 
 extern "C" int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias,
                                 float* scratch, int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize,
-                                int mode, hipStream_t stream) {
+                                int mode, float* split_ws, long split_ws_floats, hipStream_t stream) {
   DA_CLEAR_ERR();
   if (M <= 0 || N <= 0 || Cin <= 0) return DA_ERR_SHAPE;
   if ((N & 7) || (Cin & 7) || (lddy & 7) || (ldx & 7)) return DA_ERR_SHAPE;
@@ -186,7 +187,8 @@ extern "C" int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long l
     const int Kt = ksize * ksize * Cin;
     const bool big = (M >= 4096) && (N >= 160) && (Kt >= 256);
     if (g_tn_variant == 2 || g_tn_variant == 3 || (g_tn_variant == 0 && big))
-      return da_gemm_tn_v2_dispatch(g_tn_variant == 2 ? 2 : 3, dY, lddy, X, ldx, dW, dbias, M, N, Cin, Hin, Win, Hout, Wout, ksize, mode, stream);
+      return da_gemm_tn_v2_dispatch(g_tn_variant == 2 ? 2 : 3, dY, lddy, X, ldx, dW, dbias, M, N, Cin, Hin, Win, Hout, Wout, ksize, mode,
+                                    split_ws, split_ws ? split_ws_floats : 0, stream);
   }
   if (dbias) {  // small-shape path: separate fixed-order column sum
     if (!scratch) return DA_ERR_SHAPE;

@@ -26,6 +26,8 @@ struct GemmTN2Params {
   int Hin, Win, Hout, Wout, ksize, mode;
   FastDiv div_hw, div_w, div_cin;
   int tiles_n, tiles_k, splits, m_per_split;
+  float* slab;  // split > 1 with a workspace: tile partials are STORED here, [tile][split][320][BK] fp32, and summed
+               // into dW by tn_slab_reduce_kernel (no atomics; fixed summation order)
   int period;  // FAST path: the border pattern of a lane's X rows repeats every `period` 64-pixel steps
 };
 
@@ -327,7 +329,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int n = n0 + wa * 80 + i * 16 + (lane >> 4) * 4 + e;
-        if (n < p.N && kc < p.Kt) {
+        if (p.slab && p.splits > 1) {
+          // fp32 atomics retire at ~1 dword / clk / L2 channel (~48 us for the ~16 M of a 256-workgroup split grid):
+          // store the partial tile instead and let the reduce kernel add the splits
+          const int nl = wa * 80 + i * 16 + (lane >> 4) * 4 + e, kl = wb * (16 * JT) + j * 16 + (lane & 15);
+          p.slab[(((long)(tn * p.tiles_k + tk) * p.splits + split) * T2_BN + nl) * T2_BK + kl] = acc[i][j][e];
+        } else if (n < p.N && kc < p.Kt) {
           float* dst = p.dW + (long)n * p.Kt + kc;
           if (p.splits == 1) *dst += acc[i][j][e];  // sole owner of this tile: plain read-add-write
           else unsafeAtomicAdd(dst, acc[i][j][e]);
@@ -345,8 +352,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   }
 }
 
+// dW[n][k'] += sum_split slab[tile(n, k')][split][n % 320][k' % BK]   (4 consecutive k' per thread)
+template <int BK>
+__global__ __launch_bounds__(256) void tn_slab_reduce_kernel(GemmTN2Params p) {
+  const int kq = p.Kt >> 2;
+  const long total = (long)p.N * kq;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / kq);
+    const int kc = (int)(i - (long)n * kq) * 4;
+    const int tn = n / T2_BN, tk = kc / BK;
+    const float* src = p.slab + (((long)(tn * p.tiles_k + tk) * p.splits) * T2_BN + (n - tn * T2_BN)) * BK + (kc - tk * BK);
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+    int sp = 0;
+    for (; sp + 1 < p.splits; sp += 2) {
+      a += *reinterpret_cast<const f32x4*>(src + (long)sp * T2_BN * BK);
+      b += *reinterpret_cast<const f32x4*>(src + (long)(sp + 1) * T2_BN * BK);
+    }
+    if (sp < p.splits) a += *reinterpret_cast<const f32x4*>(src + (long)sp * T2_BN * BK);
+    f32x4* dst = reinterpret_cast<f32x4*>(p.dW + (long)n * p.Kt + kc);
+    *dst += a + b;
+  }
+}
+
 template <int BK, bool FAST>
-int launch_tn2(GemmTN2Params p, hipStream_t stream) {
+int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
   constexpr int SMEM = 2 * (T2_A_BYTES + T2_MS * BK * 2);
   p.tiles_n = (p.N + T2_BN - 1) / T2_BN;
   p.tiles_k = (p.Kt + BK - 1) / BK;
@@ -391,8 +420,17 @@ int launch_tn2(GemmTN2Params p, hipStream_t stream) {
       return DA_ERR_LAUNCH;
     attr_set = true;
   }
+  p.slab = nullptr;
+  if (p.splits > 1 && ws && (long)tiles * p.splits * T2_BN * BK <= ws_floats && (p.Kt & 3) == 0) p.slab = ws;
   hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST>), dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
   DA_CHECK_LAUNCH();
+  if (p.slab) {
+    const long total = (long)p.N * (p.Kt >> 2);
+    long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(tn_slab_reduce_kernel<BK>, dim3((int)blocks), dim3(256), 0, stream, p);
+    DA_CHECK_LAUNCH();
+  }
   return DA_OK;
 }
 
@@ -400,7 +438,8 @@ int launch_tn2(GemmTN2Params p, hipStream_t stream) {
 
 // Called by da_gemm_tn_wgrad (gemm_tn.hip) after argument validation.
 int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias,
-                           int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, hipStream_t stream) {
+                           int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, float* ws,
+                           long ws_floats, hipStream_t stream) {
   GemmTN2Params p;
   p.dY = (const bf16*)dY; p.X = (const bf16*)X; p.dW = dW; p.dbias = dbias;
   p.lddy = lddy; p.ldx = ldx;
@@ -410,6 +449,7 @@ int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X
   p.div_w = make_fastdiv((unsigned)Wout);
   p.div_cin = make_fastdiv((unsigned)Cin);
   p.tiles_n = p.tiles_k = p.splits = p.m_per_split = 0;
+  p.slab = nullptr;
   (void)variant;  // the 320x256 instantiation (160 accumulators) spills on gfx950 and lost to 320x192 everywhere
   const int HWo = Hout * Wout;
   p.period = 0;
@@ -417,5 +457,5 @@ int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X
     if (HWo % T2_MS == 0 && HWo / T2_MS <= 64) p.period = HWo / T2_MS;
     else if (T2_MS % HWo == 0) p.period = 1;
   }
-  return p.period ? launch_tn2<192, true>(p, stream) : launch_tn2<192, false>(p, stream);
+  return p.period ? launch_tn2<192, true>(p, ws, ws_floats, stream) : launch_tn2<192, false>(p, ws, ws_floats, stream);
 }

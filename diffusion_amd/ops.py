@@ -162,7 +162,8 @@ def gemm_tn_wgrad(dY, X, dW, g: Geom, dbias=None, scratch=None):
         db = _vec(dbias, N, 'dbias') if dbias is not None else 0
         sc = _f32buf(scratch, 256 * N * 2, 'scratch') if dbias is not None else 0
         _lib.call('da_gemm_tn_wgrad', dy_ptr, lddy, x_ptr, ldx, dW.data_ptr(), db, sc, M, N, Cin, g.Hin, g.Win,
-                  g.Hout, g.Wout, g.ksize, mode, _stream())
+                  g.Hout, g.Wout, g.ksize, mode, SPLITK_WS.data_ptr() if SPLITK_WS is not None else 0,
+                  SPLITK_WS.numel() if SPLITK_WS is not None else 0, _stream())
 
 
 def attn_fwd(Q, K, V, O, L2, B, H, Nq, Nk, scale):

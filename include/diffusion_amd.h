@@ -51,12 +51,16 @@ int da_set_option(const char* key, int value);
  * gemm_nt2_kernel with a 256x128 / 256x160 / 256x320 tile (profiling labels only) */
 int da_gemm_nt_variant_for(int M, int N, int K, int Cin, long splitk_ws_floats);
 
-/* dW[N][ksize*ksize*Cin] += sum_m dY[m][n] * gather(X)[m][k]   (fp32, atomically accumulated).
+/* dW[N][ksize*ksize*Cin] += sum_m dY[m][n] * gather(X)[m][k]   (fp32).
  * Replaces the cuDNN/cuBLAS wgrad kernels autograd runs for the same layers (loss.backward() driven by
  * Composer).  modes 0, 1, 3 as above.  If dbias != NULL, dbias[n] += sum_m dY[m][n] as well
- * (fused into the large-tile kernel; the small-shape path uses da_colsum_accum with `scratch`, >= 256*N*2 floats). */
+ * (fused into the large-tile kernel; the small-shape path uses da_colsum_accum with `scratch`, >= 256*N*2 floats).
+ * When the pixel range is split over workgroups, the partial tiles are stored in split_ws (fp32, caller-owned, may be
+ * shared with da_gemm_nt's split-K workspace on the same stream; ~64 MiB covers every split grid) and summed in a fixed
+ * order; with split_ws == NULL or too small they are accumulated with fp32 atomics instead. */
 int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, float* scratch, int M,
-                     int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, da_stream_t stream);
+                     int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, float* split_ws,
+                     long split_ws_floats, da_stream_t stream);
 
 /* softmax(Q K^T * scale) V for head_dim 64, heads at column offsets h*64 of Q/K/V/O; L2[B][H][Nq] receives the
  * per-row log2-sum-exp.  Replaces xformers memory_efficient_attention (models.py:109-111) / diffusers

@@ -282,6 +282,30 @@ def test_wgrad_v2_big(ops, dev, variant):
         ops.set_option('gemm_tn_variant', 0)
 
 
+def test_wgrad_v2_split_workspace(ops, dev):
+    """Pixel range split over workgroups with a slab workspace: partial tiles are stored and summed in a fixed order
+    (no atomics on dW) - matches the reference, accumulates into dW, and is bit-identical run to run."""
+    M, N, K = 65536, 320, 640     # 4 tiles of 320x192 -> split over the pixels
+    dy = rnd(M, N, dev=dev, seed=1, scale=0.1).to(BF); x = rnd(M, K, dev=dev, seed=2).to(BF)
+    ref = dy.float().t() @ x.float()
+    old = ops.SPLITK_WS
+    try:
+        ops.SPLITK_WS = torch.empty(24 * 1024 * 1024, device=dev, dtype=torch.float32)
+        outs = []
+        for _ in range(2):
+            dW = torch.full((N, K), 0.5, device=dev); db = torch.zeros(N, device=dev)
+            ops.gemm_tn_wgrad(dy, x, dW, ops.Geom.linear(M), dbias=db, scratch=torch.empty(256 * N * 2, device=dev))
+            outs.append(dW)
+        check(outs[0] - 0.5, ref, tol=2e-3, what='wgrad split slabs')
+        assert torch.equal(outs[0], outs[1])
+        ops.SPLITK_WS = None          # same shape through the atomic fallback
+        dW = torch.full((N, K), 0.5, device=dev)
+        ops.gemm_tn_wgrad(dy, x, dW, ops.Geom.linear(M))
+        check(dW - 0.5, ref, tol=2e-3, what='wgrad split atomics')
+    finally:
+        ops.SPLITK_WS = old
+
+
 def test_wgrad_linear_large_m(ops, dev):
     M, N, K = 5000, 136, 200
     dy = rnd(M, N, dev=dev, seed=1).to(BF)
