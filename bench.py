@@ -11,7 +11,7 @@ per-GPU batch is fixed, global batch = 256*N (2048 at N=8 = the reference's conf
 text embeddings, as the reference dataloader yields them) are resident in HBM before the timed region; timestep and
 noise draws are inside it, as in the reference's forward.  Weights are torch-default random init (seed 17).
 Prints ONE JSON line on rank 0 (see README / task contract), including `roofline` for the dominant kernel
-(the 256x320-tile implicit-GEMM gemm_nt2_kernel<8,5,2,4>: conv / linear forward + dgrad contractions) and a `cpu_baseline` (oracle port on host cores).
+(the 256x320-tile, 16-wave implicit-GEMM gemm_nt2_kernel<4,5,4,4>: conv / linear forward + dgrad contractions) and a `cpu_baseline` (oracle port on host cores).
 """
 import argparse
 import json
@@ -167,7 +167,7 @@ def main():
             if S == 32 and os.path.exists(tp):
                 with open(tp) as f:
                     pm = json.load(f)
-                key = {'gemm_nt2_kernel<8,5,2,4>': 'gemm_nt2<8,5,2,4>'}.get(dom)
+                key = {'gemm_nt2_kernel<8,5,2,4>': 'gemm_nt2<8,5,2,4>', 'gemm_nt2_kernel<4,5,4,4>': 'gemm_nt2<4,5,4,4>'}.get(dom)
                 if key in pm:
                     out['roofline']['traffic'] = round(pm[key]['hbm_bytes_per_launch_corrected'])
                     out['roofline']['traffic_source'] = 'profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)'

@@ -248,18 +248,21 @@ extern int g_tn_variant;  // gemm_tn.hip
 static int g_nt_variant = 0;
 static int g_nt_splitk = 1;  // da_set_option("gemm_nt_splitk", 0/1)  // 0 auto, 1 force v1 (128x128), 4 / 5 force v2 with BN 128 / 160 (when eligible)
 
-// 1 -> gemm_nt_kernel (128x128), 4 / 5 / 10 -> gemm_nt2_kernel with BN 128 / 160 / 320 (11: the 4-wave 128x320x32
+// 1 -> gemm_nt_kernel (128x128), 4 / 5 / 10 / 12 -> gemm_nt2_kernel with BN 128 / 160 / 320 / 320.  12 is the default
+// 256x320 form: 16 waves (4 per SIMD, 64x80 each, <= 128 VGPRs) instead of 10's 8 waves of 128x80 - the extra resident waves
+// cover LDS latency and each other's epilogues (+28-39 % on the K <= 640 linears, parity on the longest-K convs).
+// (11: the 4-wave 128x320x32
 // instantiation, forced only: two workgroups per CU stay phase-locked, so it gains <= 5 % on one K=320 shape class).  *splits > 1: split-K over
 // that many workgroups per tile (needs a workspace of splits*M*N floats) - used when the tile grid alone would
 // leave most of the 256 CUs idle (small M: low-resolution layers, small microbatches).
 static int pick_nt_variant(int M, int N, int K, int Cin, long ws_floats, int* splits) {
   *splits = 1;
   if (Cin % 64 != 0) return 1;
-  if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10 || g_nt_variant == 11) return g_nt_variant;
+  if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10 || g_nt_variant == 11 || g_nt_variant == 12) return g_nt_variant;
   if (g_nt_variant != 0) return 1;
   // one 512-thread workgroup per CU: pick the largest tile that still keeps most of the 256 CUs busy
   const long tm = (M + 255) / 256;
-  if (N % 320 == 0 && tm * (N / 320) >= 160) return 10;
+  if (N % 320 == 0 && tm * (N / 320) >= 160) return 12;
   if (N % 160 == 0 && tm * (N / 160) >= 200) return 5;
   if (N % 160 != 0 && tm * ((N + 127) / 128) >= 200) return 4;
   if (N % 320 == 0 && g_nt_splitk) {
@@ -270,7 +273,7 @@ static int pick_nt_variant(int M, int N, int K, int Cin, long ws_floats, int* sp
     while (s > 1 && (nk / s < 8 || (long)s * M * N > ws_floats)) --s;  // >= 8 K-steps per split, workspace fits
     if (s > 1 && tiles * s >= 96) {
       *splits = s;
-      return 10;
+      return 12;
     }
   }
   return 1;

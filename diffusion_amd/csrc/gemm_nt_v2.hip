@@ -56,10 +56,10 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
 // UPS: gather mode 3 (conv over a nearest-2x upsampled image) - a compile-time split so that the K loop of the other
 // modes stays one basic block.
 template <int MT, int NT, int WM, int WN, int BK, bool UPS>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt2_kernel(GemmNT2Params p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt2_kernel(GemmNT2Params p) {
   constexpr int NW = WM * WN;
   constexpr int V2_BM = 16 * MT * WM, V2_BK = BK;
-  static_assert((NW == 8 || NW == 4) && (BK == 64 || BK == 32), "wave grid");
+  static_assert((NW == 16 || NW == 8 || NW == 4) && (BK == 64 || BK == 32), "wave grid");
   constexpr int BN = 16 * NT * WN;
   constexpr int RG = 512 / BK;                // tile rows per 1-KiB DMA group (8 | 16)
   constexpr int LR = BK / 8;                  // lanes (16-B chunks) per row
@@ -238,7 +238,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt2_kernel(GemmNT2Params
   constexpr int PASSES = (TASKS + 64 * WN - 1) / (64 * WN);
   // residual rows are fetched RD strips ahead (the MFMA operand registers are dead by now): with a load -> wait ->
   // store chain per strip the epilogue exposed one HBM latency per strip, ~37 us per 256x320 tile on the K=320 linears
-  constexpr int RD = (MT < 10 / PASSES) ? MT : (10 / PASSES < 1 ? 1 : 10 / PASSES);
+  constexpr int RBUD = NW == 16 ? 3 : 10;  // 16-byte registers for the ring (128-VGPR waves get a one-strip ring)
+  constexpr int RD = (MT < RBUD / PASSES) ? MT : (RBUD / PASSES < 1 ? 1 : RBUD / PASSES);
   int trow[PASSES], tcol[PASSES];
   bool tval[PASSES];
 #pragma unroll
@@ -430,5 +431,6 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
   if (variant == 10) return launch_v2<8, 5, 2, 4, 64>(p, splits, ws, stream);
   if (variant == 11) return launch_v2<4, 10, 2, 2, 32>(p, 1, ws, stream);  // 128 x 320 x 32, 4 waves, 2 workgroups / CU
+  if (variant == 12) return launch_v2<4, 5, 4, 4, 64>(p, splits, ws, stream);  // 256 x 320 x 64, 16 waves (4 / SIMD)
   return variant == 5 ? launch_v2<4, 5, 4, 2, 64>(p, splits, ws, stream) : launch_v2<4, 4, 4, 2, 64>(p, splits, ws, stream);
 }

@@ -133,7 +133,7 @@ def test_conv_upsample_fused(ops, dev):
     check(from_nhwc(out, B, 2 * H, 2 * Wd), ref, what='up conv')
 
 
-@pytest.mark.parametrize('variant', [4, 5, 10, 11])
+@pytest.mark.parametrize('variant', [4, 5, 10, 11, 12])
 def test_gemm_nt_v2_variants(ops, dev, variant):
     """The 256x(128|160) LDS-DMA kernel forced on: linear + every conv mode, ragged M / N tails, fused epilogue."""
     ops.set_option('gemm_nt_variant', variant)
