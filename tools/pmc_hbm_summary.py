@@ -1,0 +1,48 @@
+"""Summarise the FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh into profiles/r01_pmc_hbm_traffic.json.
+HBM bytes per launch, corrected as MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes for gfx950:
+bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (FETCH_SIZE is in KiB and under-reports wide coalesced reads 2x)."""
+import csv, glob, json, re, sys, collections
+
+root = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/final'
+out = sys.argv[2] if len(sys.argv) > 2 else 'profiles/r01_pmc_hbm_traffic.json'
+
+
+def short(name):
+    m = re.search(r'(gemm_nt2_kernel|gemm_tn2_kernel)<([^>]*)>', name)
+    if m:
+        args = [a.strip() for a in m.group(2).split(',')]
+        if m.group(1) == 'gemm_nt2_kernel':
+            return 'gemm_nt2<%s>' % ','.join(args[:4])
+        return 'gemm_tn2<%s>' % args[0]
+    for k in ('attn_fwd', 'attn_bwd_dq', 'attn_bwd_dkv', 'adamw', 'geglu_bwd', 'geglu_fwd'):
+        if k in name:
+            return k
+    return None
+
+
+def load(sub, counter):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(f'{root}/{sub}/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] != counter:
+                continue
+            k = short(r['Kernel_Name'])
+            if k:
+                acc[k][0] += 1
+                acc[k][1] += float(r['Counter_Value'])
+    return acc
+
+
+fe, wr = load('pmc_fetch', 'FETCH_SIZE'), load('pmc_write', 'WRITE_SIZE')
+res = {}
+for k in sorted(fe):
+    n = fe[k][0]
+    f_kb = fe[k][1] / n
+    w_kb = wr[k][1] / wr[k][0] if k in wr and wr[k][0] else 0.0
+    res[k] = {'launches': n, 'fetch_KB_raw_per_launch': f_kb, 'write_KB_per_launch': w_kb,
+              'hbm_bytes_per_launch_corrected': (2 * f_kb + w_kb) * 1024}
+res['_note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1` '
+                '(tools/collect_profiles.sh); per-launch means over both steps. Correction per MI355X_MICROARCH.md (HBM section): '
+                'bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950).')
+json.dump(res, open(out, 'w'), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != '_note'}, indent=1)[:1500])
