@@ -33,6 +33,9 @@ struct GemmNT2Params {
   int tiles_m, tiles_n;
   int splits, ksteps_per_split;  // split-K: workgroup (tile, s) multiplies K-steps [s*kps, (s+1)*kps) into slab s
   long slab_stride;              // elements between fp32 partial slabs (split-K only)
+  bf16* G;                       // GEGLU variant: gated output [M][inner] (C then holds the pre-activation [M][2*inner])
+  long ldg;
+  int inner;                     // GEGLU variant: hidden width; W rows [0, inner) = value, [inner, 2*inner) = gate
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
@@ -55,7 +58,11 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
 // epilogue overlap the other's MFMAs.
 // UPS: gather mode 3 (conv over a nearest-2x upsampled image) - a compile-time split so that the K loop of the other
 // modes stays one basic block.
-template <int MT, int NT, int WM, int WN, int BK, bool UPS>
+// GEGLU: the feed-forward input projection with its activation fused (diffusers GEGLU: out = value * gelu(gate)).  A
+// column tile is the 160 value rows of 160 hidden units followed by their 160 gate rows of W (the per-lane row offsets
+// make that remap free), so both halves of every product sit in the same LDS strip; the epilogue stores the bf16
+// pre-activation (kept for backward) and the gated output, which saves the separate pass that re-read the former.
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, bool GEGLU = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt2_kernel(GemmNT2Params p) {
   constexpr int NW = WM * WN;
   constexpr int V2_BM = 16 * MT * WM, V2_BK = BK;
@@ -86,6 +93,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
   }
   const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
   const int m0 = tm * V2_BM, n0 = tn * BN;
+  // weight / bias row behind tile column c (GEGLU: 160 value rows, then the 160 matching gate rows)
+  auto wrow = [&](int c) {
+    if constexpr (GEGLU) return c < BN / 2 ? tn * (BN / 2) + c : p.inner + tn * (BN / 2) + (c - BN / 2);
+    else return n0 + c;
+  };
   const int HWo = p.Hout * p.Wout;
   const int pad = (p.ksize == 3) ? 1 : 0;
   const int gmul = (p.mode == 1) ? 2 : 1, gshift = (p.mode >= 2) ? 1 : 0, pmask = (p.mode == 2) ? 1 : 0;
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   // bias for this column block -> LDS (behind the stage buffers), read back in the epilogue; zeros when absent
   if (tid < BN / 4) {
-    const int n = n0 + tid * 4;
+    const int n = wrow(tid * 4);
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
     *reinterpret_cast<f32x4*>(smem + 2 * STAGE + tid * 16) = bv;
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
   for (int j = 0; j < BJ; ++j) {
     const int g = wave + NW * j;
     const int row = g * RG + lrow;
-    const int n = min(n0 + row, p.N - 1);
+    const int n = min(wrow(row), p.N - 1);
     woff[j] = (unsigned)n * (unsigned)p.K + (lchunk ^ swz_key<BK>(row)) * 8;
   }
 
@@ -225,6 +237,54 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
       compute_half(t & 1, 0);
     }
     __syncthreads();  // vmcnt(0): step t+1 has landed; barrier: everyone is done reading stage t
+  }
+
+  if constexpr (GEGLU) {
+    static_assert(BN == 320 && !UPS, "GEGLU tile = 160 value + 160 gate columns");
+    constexpr int GLD = BN + 4, GSTRIP = 16 * GLD, HC = BN / 2;  // strip layout as below; HC hidden units per tile
+    constexpr int GTASKS = 16 * (HC / 8), GPASSES = (GTASKS + 64 * WN - 1) / (64 * WN);
+    const float* bl = reinterpret_cast<const float*>(smem + 2 * STAGE);
+    const int mrow0g = m0 + wm * (16 * MT);
+    const int h0 = tn * HC;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float* ew = reinterpret_cast<float*>(smem) + wm * GSTRIP;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          ew[((lane >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (lane & 15)] = acc[i][j][e];
+      __syncthreads();
+#pragma unroll
+      for (int pss = 0; pss < GPASSES; ++pss) {
+        const int task = wn * 64 + lane + 64 * WN * pss;
+        const int row = task / (HC / 8), c8 = (task - row * (HC / 8)) * 8;
+        const int m = mrow0g + i * 16 + row;
+        if (task < GTASKS && m < p.M && h0 + c8 < p.inner) {
+          bf16x8 fv, fg, og;
+#pragma unroll
+          for (int q4 = 0; q4 < 2; ++q4) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(&ew[row * GLD + c8 + 4 * q4]);
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(&ew[row * GLD + HC + c8 + 4 * q4]);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bl + c8 + 4 * q4);
+            const f32x4 bg = *reinterpret_cast<const f32x4*>(bl + HC + c8 + 4 * q4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // rounded to bf16 BEFORE gating, exactly as the two-kernel path (da_gemm_nt then da_geglu_fwd) does
+              fv[4 * q4 + e] = f2bf(v4[e] * p.alpha + bv[e]);
+              fg[4 * q4 + e] = f2bf(g4[e] * p.alpha + bg[e]);
+              og[4 * q4 + e] = f2bf(bf2f(fv[4 * q4 + e]) * gelu_f(bf2f(fg[4 * q4 + e])));
+            }
+          }
+          bf16* fp = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + h0 + c8;
+          st8(fp, fv);
+          st8(fp + p.inner, fg);
+          st8(p.G + (long)m * p.ldg + h0 + c8, og);
+        }
+      }
+      __syncthreads();  // single strip buffer: everyone is done reading before it is rewritten
+    }
+    return;
   }
 
   // ---- epilogue: the WN waves that share a row block stage their i-th 16-row MFMA strip side by side in LDS, then
@@ -407,6 +467,24 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
   return DA_OK;
 }
 
+int launch_v2_geglu(GemmNT2Params p, hipStream_t stream) {
+  constexpr int BN = 320, SMEM = 2 * (256 * 64 * 2 + BN * 64 * 2) + BN * 4;
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.inner + BN / 2 - 1) / (BN / 2);
+  p.splits = 1;
+  p.ksteps_per_split = p.K / 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<4, 5, 4, 4, 64, false, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      return DA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt2_kernel<4, 5, 4, 4, 64, false, true>), dim3(p.tiles_m * p.tiles_n), dim3(1024), SMEM, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
 template <int MT, int NT, int WM, int WN, int BK>
 int launch_v2(const GemmNT2Params& p, int splits, float* ws, hipStream_t stream) {
   return p.mode == 3 ? launch_v2_mode<MT, NT, WM, WN, BK, true>(p, splits, ws, stream)
@@ -429,8 +507,28 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
   p.ksize = ksize; p.mode = mode; p.out_fp32 = out_fp32; p.alpha = alpha;
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
+  p.G = nullptr; p.ldg = 0; p.inner = 0;
   if (variant == 10) return launch_v2<8, 5, 2, 4, 64>(p, splits, ws, stream);
   if (variant == 11) return launch_v2<4, 10, 2, 2, 32>(p, 1, ws, stream);  // 128 x 320 x 32, 4 waves, 2 workgroups / CU
   if (variant == 12) return launch_v2<4, 5, 4, 4, 64>(p, splits, ws, stream);  // 256 x 320 x 64, 16 waves (4 / SIMD)
   return variant == 5 ? launch_v2<4, 5, 4, 2, 64>(p, splits, ws, stream) : launch_v2<4, 4, 4, 2, 64>(p, splits, ws, stream);
+}
+
+/* F[M][2*inner] = A[M][K] . W[2*inner][K]^T + bias ; G[M][inner] = F[:, :inner] * gelu(F[:, inner:]) in one launch */
+extern "C" int da_gemm_nt_geglu(const void* A, long lda, const void* W, void* F, long ldf, void* G, long ldg,
+                                const float* bias, int M, int inner, int K, hipStream_t stream) {
+  DA_CLEAR_ERR();
+  if (M <= 0 || inner <= 0 || K <= 0) return DA_ERR_SHAPE;
+  if ((inner % 160) || (K % 64) || (lda & 7) || (ldf & 7) || (ldg & 7)) return DA_ERR_SHAPE;
+  GemmNT2Params p;
+  p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = F; p.bias = bias;
+  p.rowbias = nullptr; p.R = nullptr;
+  p.lda = lda; p.ldc = ldf; p.ldrb = 0; p.ldr = 0;
+  p.M = M; p.N = 2 * inner; p.K = K; p.Cin = K;
+  p.Hin = 1; p.Win = 1; p.Hout = 1; p.Wout = 1;
+  p.ksize = 1; p.mode = 0; p.out_fp32 = 0; p.alpha = 1.0f;
+  p.tiles_m = p.tiles_n = 0;
+  p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
+  p.G = (bf16*)G; p.ldg = ldg; p.inner = inner;
+  return launch_v2_geglu(p, stream);
 }

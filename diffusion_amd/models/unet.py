@@ -559,9 +559,13 @@ class UNetHIP(nn.Module):
         h2 = self._lin_fwd(o2, tb + '.attn2.to_out.0', residual=h1)
         # feed-forward (GEGLU)
         n3, ln3 = self._ln_fwd(h2, tb + '.norm3')
-        f = self._lin_fwd(n3, tb + '.ff.net.0.proj')
         gg = self._bf(M, 4 * C)
-        ops.geglu_fwd(f, gg)
+        if ops.geglu_fusable(4 * C, C):   # projection + GEGLU gate in one launch (saves the pass that re-reads f)
+            f = self._bf(M, 8 * C)
+            ops.gemm_nt_geglu(n3, self.M(tb + '.ff.net.0.proj.weight').w, f, gg, self.V(tb + '.ff.net.0.proj.bias').p)
+        else:
+            f = self._lin_fwd(n3, tb + '.ff.net.0.proj')
+            ops.geglu_fwd(f, gg)
         h3 = self._lin_fwd(gg, tb + '.ff.net.2', residual=h2)
         y = self._lin_fwd(h3, p + '.proj_out', out=out, residual=x)
         saved = (p, x, gst, g, h0, ln1, n1, qkv, o1, l1, h1, ln2, n2, q2, kv2, o2, l2, h2, ln3, n3, f, gg, h3, B, H, W,

@@ -145,6 +145,28 @@ def gemm_nt(A, W, out, g: Geom, *, bias=None, rowbias=None, residual=None, alpha
     return out
 
 
+def geglu_fusable(inner: int, K: int) -> bool:
+    """shapes da_gemm_nt_geglu accepts (160 hidden units per column tile, 64-deep K steps)"""
+    return inner % 160 == 0 and K % 64 == 0
+
+
+def gemm_nt_geglu(A, W, F, G, bias):
+    """F[M, 2*inner] = A @ W^T + bias ; G[M, inner] = F[:, :inner] * gelu(F[:, inner:]) - one launch."""
+    a_ptr, lda = _mat(A, BF16, 'A')
+    w_ptr, ldw = _mat(W, BF16, 'W')
+    f_ptr, ldf = _mat(F, BF16, 'F')
+    g_ptr, ldg = _mat(G, BF16, 'G')
+    M, K = A.shape
+    inner = G.shape[1]
+    if tuple(W.shape) != (2 * inner, K) or ldw != K or tuple(F.shape) != (M, 2 * inner) or G.shape[0] != M:
+        raise ValueError('gemm_nt_geglu: shape mismatch')
+    if not geglu_fusable(inner, K):
+        raise ValueError(f'gemm_nt_geglu needs inner % 160 == 0 and K % 64 == 0, got {inner}, {K}')
+    with _Timed('gemm_nt2_kernel<4,5,4,4>', 2.0 * M * 2 * inner * K, (M, 2 * inner, K, 1, 'geglu')):
+        _lib.call('da_gemm_nt_geglu', a_ptr, lda, w_ptr, f_ptr, ldf, g_ptr, ldg, _vec(bias, 2 * inner, 'bias'), M, inner,
+                  K, _stream())
+
+
 def gemm_tn_wgrad(dY, X, dW, g: Geom, dbias=None, scratch=None):
     """dW[N, k*k*Cin] (fp32) += dY^T @ gather(X);  optionally dbias[N] += column sums of dY (fused)."""
     dy_ptr, lddy = _mat(dY, BF16, 'dY')

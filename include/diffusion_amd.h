@@ -43,6 +43,13 @@ int da_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const 
                int ksize, int mode, int out_fp32, float alpha, float* splitk_ws, long splitk_ws_floats,
                da_stream_t stream);
 
+/* Feed-forward input projection with its GEGLU activation fused (diffusers FeedForward.net.0 = GEGLU.proj + gelu gate,
+ * reached from stable_diffusion.py:183): F[M][2*inner] = A[M][K] . W[2*inner][K]^T + bias (bf16, kept for backward) and
+ * G[M][inner] = F[:, :inner] * gelu_erf(F[:, inner:]) in one launch; bit-identical to da_gemm_nt followed by
+ * da_geglu_fwd.  Requires inner % 160 == 0 and K % 64 == 0 (DA_ERR_SHAPE otherwise: use the two calls). */
+int da_gemm_nt_geglu(const void* A, long lda, const void* W, void* F, long ldf, void* G, long ldg, const float* bias,
+                     int M, int inner, int K, da_stream_t stream);
+
 /* tuning / test hook: "gemm_nt_variant" = 0 auto, 1 force the 128x128 kernel, 4 / 5 force the 256x128 / 256x160
  * LDS-DMA kernel where eligible (Cin % 64 == 0); "gemm_tn_variant" = 0 auto, 1 force the 128x128x32 wgrad kernel,
  * 2 force the 320x192x64 LDS-DMA wgrad kernel.  Returns DA_ERR_SHAPE for unknown keys. */

@@ -133,6 +133,23 @@ def test_conv_upsample_fused(ops, dev):
     check(from_nhwc(out, B, 2 * H, 2 * Wd), ref, what='up conv')
 
 
+def test_gemm_nt_geglu_fused(ops, dev):
+    """projection + GEGLU in one launch == da_gemm_nt followed by da_geglu_fwd, bit for bit (ragged M, strided input)."""
+    M, K, inner = 1000, 320, 1280
+    buf = rnd(M, K + 64, dev=dev, seed=1).to(BF); A = buf[:, 32:32 + K]
+    W = rnd(2 * inner, K, dev=dev, seed=2, scale=K**-0.5).to(BF); bias = rnd(2 * inner, dev=dev, seed=3)
+    f_ref = torch.empty(M, 2 * inner, device=dev, dtype=BF); g_ref = torch.empty(M, inner, device=dev, dtype=BF)
+    ops.gemm_nt(A, W, f_ref, ops.Geom.linear(M), bias=bias)
+    ops.geglu_fwd(f_ref, g_ref)
+    f = torch.zeros_like(f_ref); g = torch.zeros_like(g_ref)
+    ops.gemm_nt_geglu(A, W, f, g, bias)
+    assert torch.equal(f, f_ref) and torch.equal(g, g_ref)
+    h = A.float() @ W.float().t() + bias
+    check(g, h[:, :inner] * F.gelu(h[:, inner:]), what='fused geglu vs fp32')
+    with pytest.raises(ValueError):
+        ops.gemm_nt_geglu(A, W[:2 * 136], f[:, :2 * 136], g[:, :136], bias[:2 * 136])
+
+
 @pytest.mark.parametrize('variant', [4, 5, 10, 11, 12])
 def test_gemm_nt_v2_variants(ops, dev, variant):
     """The 256x(128|160) LDS-DMA kernel forced on: linear + every conv mode, ragged M / N tails, fused epilogue."""
