@@ -19,6 +19,7 @@ SIGNATURES = {
     'da_set_option': [C.c_char_p, _i],
     'da_gemm_nt_variant_for': [_i, _i, _i, _i, _l],
     'da_gemm_nt_geglu': [_vp, _l, _vp, _vp, _l, _vp, _l, _fp, _i, _i, _i, _vp],
+    'da_gemm_nt_geglu_bwd': [_vp, _l, _vp, _vp, _l, _vp, _l, _i, _i, _i, _vp],
     'da_gemm_tn_wgrad': [_vp, _l, _vp, _l, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _l, _vp],
     'da_attn_fwd': [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _fp, _i, _i, _i, _i, _f, _vp],
     'da_attn_bwd': [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _fp, _fp, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i,

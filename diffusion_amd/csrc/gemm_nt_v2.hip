@@ -62,7 +62,9 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
 // column tile is the 160 value rows of 160 hidden units followed by their 160 gate rows of W (the per-lane row offsets
 // make that remap free), so both halves of every product sit in the same LDS strip; the epilogue stores the bf16
 // pre-activation (kept for backward) and the gated output, which saves the separate pass that re-read the former.
-template <int MT, int NT, int WM, int WN, int BK, bool UPS, bool GEGLU = false>
+// GEGLU == 2 is the backward counterpart on the dgrad of the FF output projection: the tile of d(gated) never goes to
+// HBM; the epilogue reads the saved pre-activation, applies the GEGLU derivative and stores d(pre-activation).
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt2_kernel(GemmNT2Params p) {
   constexpr int NW = WM * WN;
   constexpr int V2_BM = 16 * MT * WM, V2_BK = BK;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
   const int m0 = tm * V2_BM, n0 = tn * BN;
   // weight / bias row behind tile column c (GEGLU: 160 value rows, then the 160 matching gate rows)
   auto wrow = [&](int c) {
-    if constexpr (GEGLU) return c < BN / 2 ? tn * (BN / 2) + c : p.inner + tn * (BN / 2) + (c - BN / 2);
+    if constexpr (GEGLU == 1) return c < BN / 2 ? tn * (BN / 2) + c : p.inner + tn * (BN / 2) + (c - BN / 2);
     else return n0 + c;
   };
   const int HWo = p.Hout * p.Wout;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
     __syncthreads();  // vmcnt(0): step t+1 has landed; barrier: everyone is done reading stage t
   }
 
-  if constexpr (GEGLU) {
+  if constexpr (GEGLU == 1) {
     static_assert(BN == 320 && !UPS, "GEGLU tile = 160 value + 160 gate columns");
     constexpr int GLD = BN + 4, GSTRIP = 16 * GLD, HC = BN / 2;  // strip layout as below; HC hidden units per tile
     constexpr int GTASKS = 16 * (HC / 8), GPASSES = (GTASKS + 64 * WN - 1) / (64 * WN);
@@ -283,6 +285,62 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
         }
       }
       __syncthreads();  // single strip buffer: everyone is done reading before it is rewritten
+    }
+    return;
+  }
+
+  if constexpr (GEGLU == 2) {
+    // C = d(pre-activation) [M][2*inner], G = saved pre-activation F [M][2*inner] (read only), tile = 320 columns of
+    // d(gated); arithmetic and rounding points as da_geglu_bwd on a bf16 d(gated)
+    constexpr int GLD = BN + 4, GSTRIP = 16 * GLD, CHB = BN / 8;
+    constexpr int GTASKS = 16 * CHB, GPASSES = (GTASKS + 64 * WN - 1) / (64 * WN);
+    const int mrow0g = m0 + wm * (16 * MT);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float* ew = reinterpret_cast<float*>(smem) + wm * GSTRIP;
+      bf16x8 fa[GPASSES], fg[GPASSES];  // this strip's saved value / gate rows, in flight across the LDS exchange
+#pragma unroll
+      for (int pss = 0; pss < GPASSES; ++pss) {
+        const int task = wn * 64 + lane + 64 * WN * pss;
+        const int row = task / CHB, c8 = (task - row * CHB) * 8;
+        const int m = mrow0g + i * 16 + row;
+        fa[pss] = zero8();
+        fg[pss] = zero8();
+        if (task < GTASKS && m < p.M && n0 + c8 < p.inner) {
+          const bf16* fp = p.G + (long)m * p.ldg + n0 + c8;
+          fa[pss] = ld8(fp);
+          fg[pss] = ld8(fp + p.inner);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          ew[((lane >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (lane & 15)] = acc[i][j][e];
+      __syncthreads();
+#pragma unroll
+      for (int pss = 0; pss < GPASSES; ++pss) {
+        const int task = wn * 64 + lane + 64 * WN * pss;
+        const int row = task / CHB, c8 = (task - row * CHB) * 8;
+        const int m = mrow0g + i * 16 + row;
+        if (task < GTASKS && m < p.M && n0 + c8 < p.inner) {
+          bf16x8 da, dg;
+#pragma unroll
+          for (int q4 = 0; q4 < 2; ++q4) {
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(&ew[row * GLD + c8 + 4 * q4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float df = bf2f(f2bf(d4[e] * p.alpha)), gf = bf2f(fg[pss][4 * q4 + e]);
+              da[4 * q4 + e] = f2bf(df * gelu_f(gf));
+              dg[4 * q4 + e] = f2bf(df * bf2f(fa[pss][4 * q4 + e]) * dgelu_f(gf));
+            }
+          }
+          bf16* op = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n0 + c8;
+          st8(op, da);
+          st8(op + p.inner, dg);
+        }
+      }
+      __syncthreads();
     }
     return;
   }
@@ -467,20 +525,21 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
   return DA_OK;
 }
 
+template <int GM>
 int launch_v2_geglu(GemmNT2Params p, hipStream_t stream) {
   constexpr int BN = 320, SMEM = 2 * (256 * 64 * 2 + BN * 64 * 2) + BN * 4;
   p.tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.inner + BN / 2 - 1) / (BN / 2);
+  p.tiles_n = GM == 1 ? (p.inner + BN / 2 - 1) / (BN / 2) : (p.inner + BN - 1) / BN;
   p.splits = 1;
   p.ksteps_per_split = p.K / 64;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<4, 5, 4, 4, 64, false, true>,
+    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<4, 5, 4, 4, 64, false, GM>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return DA_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt2_kernel<4, 5, 4, 4, 64, false, true>), dim3(p.tiles_m * p.tiles_n), dim3(1024), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_nt2_kernel<4, 5, 4, 4, 64, false, GM>), dim3(p.tiles_m * p.tiles_n), dim3(1024), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -530,5 +589,24 @@ extern "C" int da_gemm_nt_geglu(const void* A, long lda, const void* W, void* F,
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
   p.G = (bf16*)G; p.ldg = ldg; p.inner = inner;
-  return launch_v2_geglu(p, stream);
+  return launch_v2_geglu<1>(p, stream);
+}
+
+/* dF[M][2*inner] = geglu_bwd(F, dG) with dG[M][inner] = dY[M][K] . Wt[inner][K]^T never written to HBM */
+extern "C" int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* F, long ldf, void* dF, long lddf,
+                                    int M, int inner, int K, hipStream_t stream) {
+  DA_CLEAR_ERR();
+  if (M <= 0 || inner <= 0 || K <= 0) return DA_ERR_SHAPE;
+  if ((inner % 320) || (K % 64) || (lddy & 7) || (ldf & 7) || (lddf & 7)) return DA_ERR_SHAPE;
+  GemmNT2Params p;
+  p.A = (const bf16*)dY; p.W = (const bf16*)Wt; p.C = dF; p.bias = nullptr;
+  p.rowbias = nullptr; p.R = nullptr;
+  p.lda = lddy; p.ldc = lddf; p.ldrb = 0; p.ldr = 0;
+  p.M = M; p.N = inner; p.K = K; p.Cin = K;
+  p.Hin = 1; p.Win = 1; p.Hout = 1; p.Wout = 1;
+  p.ksize = 1; p.mode = 0; p.out_fp32 = 0; p.alpha = 1.0f;
+  p.tiles_m = p.tiles_n = 0;
+  p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
+  p.G = (bf16*)const_cast<void*>(F); p.ldg = ldf; p.inner = inner;
+  return launch_v2_geglu<2>(p, stream);
 }

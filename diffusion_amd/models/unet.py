@@ -581,10 +581,14 @@ class UNetHIP(nn.Module):
         tb = p + '.transformer_blocks.0'
         nk = self._ctx.shape[0] // B
         dh3 = self._lin_bwd(h3, dout, p + '.proj_out')
-        dgg = self._lin_bwd(gg, dh3, tb + '.ff.net.2')
         df = self._bf(M, 8 * C)
-        ops.geglu_bwd(f, dgg, df)
-        del dgg
+        if ops.geglu_bwd_fusable(4 * C, C):   # dgrad of ff.net.2 with the GEGLU derivative in its epilogue
+            self._lin_bwd(gg, dh3, tb + '.ff.net.2', need_dx=False)
+            ops.gemm_nt_geglu_bwd(dh3, self.M(tb + '.ff.net.2.weight').wt, f, df)
+        else:
+            dgg = self._lin_bwd(gg, dh3, tb + '.ff.net.2')
+            ops.geglu_bwd(f, dgg, df)
+            del dgg
         dn3 = self._lin_bwd(n3, df, tb + '.ff.net.0.proj')
         del df
         dh2 = self._ln_bwd(h2, dn3, dh3, tb + '.norm3', ln3)

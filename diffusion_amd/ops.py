@@ -167,6 +167,26 @@ def gemm_nt_geglu(A, W, F, G, bias):
                   K, _stream())
 
 
+def geglu_bwd_fusable(inner: int, K: int) -> bool:
+    return inner % 320 == 0 and K % 64 == 0
+
+
+def gemm_nt_geglu_bwd(dY, Wt, F, dF):
+    """dF[M, 2*inner] = geglu_bwd(F, dY @ Wt^T) with the [M, inner] product never written to HBM.  Wt: [inner, K]."""
+    dy_ptr, lddy = _mat(dY, BF16, 'dY')
+    w_ptr, ldw = _mat(Wt, BF16, 'Wt')
+    f_ptr, ldf = _mat(F, BF16, 'F')
+    df_ptr, lddf = _mat(dF, BF16, 'dF')
+    M, K = dY.shape
+    inner = Wt.shape[0]
+    if ldw != K or Wt.shape[1] != K or tuple(F.shape) != (M, 2 * inner) or tuple(dF.shape) != (M, 2 * inner):
+        raise ValueError('gemm_nt_geglu_bwd: shape mismatch')
+    if not geglu_bwd_fusable(inner, K):
+        raise ValueError(f'gemm_nt_geglu_bwd needs inner % 320 == 0 and K % 64 == 0, got {inner}, {K}')
+    with _Timed('gemm_nt2_kernel<4,5,4,4>', 2.0 * M * inner * K, (M, inner, K, 1, 'geglu_bwd')):
+        _lib.call('da_gemm_nt_geglu_bwd', dy_ptr, lddy, w_ptr, f_ptr, ldf, df_ptr, lddf, M, inner, K, _stream())
+
+
 def gemm_tn_wgrad(dY, X, dW, g: Geom, dbias=None, scratch=None):
     """dW[N, k*k*Cin] (fp32) += dY^T @ gather(X);  optionally dbias[N] += column sums of dY (fused)."""
     dy_ptr, lddy = _mat(dY, BF16, 'dY')

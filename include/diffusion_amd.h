@@ -50,6 +50,12 @@ int da_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const 
 int da_gemm_nt_geglu(const void* A, long lda, const void* W, void* F, long ldf, void* G, long ldg, const float* bias,
                      int M, int inner, int K, da_stream_t stream);
 
+/* Backward counterpart on the dgrad of FeedForward.net.2: dG[M][inner] = dY[M][K] . Wt[inner][K]^T is gated against the
+ * saved pre-activation F[M][2*inner] in the epilogue and leaves as dF[M][2*inner] (= da_geglu_bwd(F, dG)) without dG
+ * ever reaching HBM; bit-identical to da_gemm_nt followed by da_geglu_bwd.  Requires inner % 320 == 0, K % 64 == 0. */
+int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* F, long ldf, void* dF, long lddf, int M,
+                         int inner, int K, da_stream_t stream);
+
 /* tuning / test hook: "gemm_nt_variant" = 0 auto, 1 force the 128x128 kernel, 4 / 5 force the 256x128 / 256x160
  * LDS-DMA kernel where eligible (Cin % 64 == 0); "gemm_tn_variant" = 0 auto, 1 force the 128x128x32 wgrad kernel,
  * 2 force the 320x192x64 LDS-DMA wgrad kernel.  Returns DA_ERR_SHAPE for unknown keys. */

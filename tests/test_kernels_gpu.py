@@ -150,6 +150,24 @@ def test_gemm_nt_geglu_fused(ops, dev):
         ops.gemm_nt_geglu(A, W[:2 * 136], f[:, :2 * 136], g[:, :136], bias[:2 * 136])
 
 
+def test_gemm_nt_geglu_bwd_fused(ops, dev):
+    """dgrad of the FF output projection + GEGLU derivative in one launch == da_gemm_nt then da_geglu_bwd, bit for bit."""
+    M, K, inner = 1000, 320, 1280
+    dy = rnd(M, K, dev=dev, seed=1).to(BF)
+    wt = rnd(inner, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
+    f = rnd(M, 2 * inner, dev=dev, seed=3, scale=1.5).to(BF)
+    dgg = torch.empty(M, inner, device=dev, dtype=BF); ref = torch.empty(M, 2 * inner, device=dev, dtype=BF)
+    ops.gemm_nt(dy, wt, dgg, ops.Geom.linear(M))
+    ops.geglu_bwd(f, dgg, ref)
+    got = torch.zeros_like(ref)
+    ops.gemm_nt_geglu_bwd(dy, wt, f, got)
+    assert torch.equal(got, ref)
+    a = f[:, :inner].float().requires_grad_(True); g = f[:, inner:].float().requires_grad_(True)
+    (a * F.gelu(g)).backward(dy.float() @ wt.float().t())
+    check(got[:, :inner], a.grad, what='fused geglu bwd d(value)')
+    check(got[:, inner:], g.grad, what='fused geglu bwd d(gate)')
+
+
 @pytest.mark.parametrize('variant', [4, 5, 10, 11, 12])
 def test_gemm_nt_v2_variants(ops, dev, variant):
     """The 256x(128|160) LDS-DMA kernel forced on: linear + every conv mode, ragged M / N tails, fused epilogue."""
