@@ -24,15 +24,37 @@ class FusedAdamW(torch.optim.Optimizer):
         self.ema_smoothing = 0.0
         self.ema_update_this_step = False
 
+    # The update can be issued in slices as gradients become final (trainer + parallel.BucketedAllReducer hand over
+    # [lo, hi) ranges back-to-front during the last microbatch's backward, on the reducer's side stream), so the
+    # HBM-bound optimizer pass hides under the remaining backward GEMMs instead of trailing the step.
     @torch.no_grad()
-    def step(self, closure=None):
+    def begin_step(self):
+        """Open optimizer step number opt_step+1; nothing updated yet."""
+        self.unet.opt_step += 1
+        self._pending_hi = self.unet.master.numel()
+        self._open = True
+
+    @torch.no_grad()
+    def step_range(self, lo: int, hi: int):
+        """AdamW (+ bf16 shadow, + EMA) on flat offsets [lo, hi) of the step opened by begin_step()."""
+        if hi <= lo:
+            return
         g = self.param_groups[0]
         u = self.unet
-        u.opt_step += 1
-        ops.adamw(u.master, u.grad, u.exp_avg, u.exp_avg_sq, u.shadow, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
-                  g['weight_decay'], u.opt_step, self.grad_scale,
-                  ema=self.ema if self.ema_update_this_step else None, ema_smoothing=self.ema_smoothing)
-        u.refresh_transposed()
+        ema = self.ema[lo:hi] if (self.ema is not None and self.ema_update_this_step) else None
+        ops.adamw(u.master[lo:hi], u.grad[lo:hi], u.exp_avg[lo:hi], u.exp_avg_sq[lo:hi], u.shadow[lo:hi], g['lr'],
+                  g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], u.opt_step, self.grad_scale,
+                  ema=ema, ema_smoothing=self.ema_smoothing)
+        self._pending_hi = min(self._pending_hi, lo)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        """Update everything begin_step()/step_range() have not covered yet, then refresh the dgrad weight shadow."""
+        if not getattr(self, '_open', False):
+            self.begin_step()
+        self.step_range(0, self._pending_hi)
+        self._open = False
+        self.unet.refresh_transposed()
 
     def zero_grad(self, set_to_none: bool = False):
         self.unet.grad.zero_()

@@ -33,6 +33,8 @@ class BucketedAllReducer:
         self.handles: List = []
         self.launched: List = []  # (lo, hi) ranges, for tests
         self.stream: Optional[torch.cuda.Stream] = torch.cuda.Stream() if flat_grad.is_cuda else None
+        # optional per-bucket continuation, run stream-ordered behind the bucket's all-reduce (e.g. its AdamW slice)
+        self.on_bucket = None
 
     @property
     def world_size(self) -> int:
@@ -47,7 +49,7 @@ class BucketedAllReducer:
         if hi <= lo:
             return
         self.launched.append((lo, hi))
-        if not self.enabled:
+        if not self.enabled and self.on_bucket is None:
             return
         view = self.flat[lo:hi]
         if self.stream is not None:
@@ -55,9 +57,23 @@ class BucketedAllReducer:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
-                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.enabled:
+                    h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    if self.on_bucket is not None:
+                        h.wait()  # orders the side stream behind the collective; the continuation follows on it
+                    else:
+                        self.handles.append(h)
+                if self.on_bucket is not None:
+                    self.on_bucket(lo, hi)
         else:
-            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.enabled:
+                h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.on_bucket is not None:
+                    h.wait()
+                else:
+                    self.handles.append(h)
+            if self.on_bucket is not None:
+                self.on_bucket(lo, hi)
 
     def ready(self, lo: int):
         """Every gradient at flat offsets >= lo is final."""
@@ -72,7 +88,7 @@ class BucketedAllReducer:
         self.hi = 0
         for h in self.handles:
             h.wait()
-        if self.stream is not None and self.enabled:
+        if self.stream is not None and (self.enabled or self.on_bucket is not None):
             torch.cuda.current_stream().wait_stream(self.stream)
         self.handles.clear()
 

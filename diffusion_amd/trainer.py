@@ -108,6 +108,7 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.reducer = BucketedAllReducer(model.unet.grad)
+        self.sliced_optimizer = os.environ.get('DA_SLICED_ADAMW', '0') == '1'
         self.base_lr = self.optimizer.param_groups[0]['lr']
         self.global_batch_size = None
         self.logs: List[dict] = []
@@ -129,25 +130,37 @@ class Trainer:
         total = torch.zeros((), device=unet.device_)
         starts = list(range(0, n, mb))
         self.reducer.begin()
+        opt = self.optimizer
+        # AdamW slices behind each gradient bucket on the side stream: measured 196.4 vs 196.6 ms/step at N=1 (and 202 ms
+        # with per-kernel events) - the slices only take CUs from the backward GEMMs - so it is opt-in
+        sliced = self.sliced_optimizer and hasattr(opt, 'step_range')
         for i, s in enumerate(starts):
             sub = {k: (v[s:s + mb] if torch.is_tensor(v) else v) for k, v in batch.items()}
             w = min(mb, n - s) / n
             outputs = model(sub)
             loss = model.loss(outputs, sub, weight=w)
-            unet._grad_ready_cb = self.reducer.ready if i == len(starts) - 1 else None
+            last = i == len(starts) - 1
+            if last:
+                # everything the optimizer step needs is known before the last backward: each gradient bucket is
+                # all-reduced and its AdamW slice issued on the side stream as soon as backward has finished it
+                if self.scheduler is not None:
+                    bpe = len(self.dataloader) if hasattr(self.dataloader, '__len__') else None
+                    opt.param_groups[0]['lr'] = self.base_lr * self.scheduler(self.batch_idx, bpe)
+                opt.grad_scale = 1.0 / self.world
+                for a in self.algorithms:
+                    a.before_optimizer_step(self)
+                if sliced:
+                    opt.begin_step()
+                    self.reducer.on_bucket = opt.step_range
+            unet._grad_ready_cb = self.reducer.ready if last else None
             model.backward_from_loss()
             for m in model.get_metrics(is_train=True).values():
                 model.update_metric(sub, outputs, m)
             total = total + loss.detach() * w
         unet._grad_ready_cb = None
         self.reducer.flush()
-        if self.scheduler is not None:
-            bpe = len(self.dataloader) if hasattr(self.dataloader, '__len__') else None
-            self.optimizer.param_groups[0]['lr'] = self.base_lr * self.scheduler(self.batch_idx, bpe)
-        self.optimizer.grad_scale = 1.0 / self.world
-        for a in self.algorithms:
-            a.before_optimizer_step(self)
-        self.optimizer.step()
+        self.reducer.on_bucket = None
+        opt.step()
         return total
 
     def fit(self):

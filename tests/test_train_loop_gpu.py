@@ -54,3 +54,40 @@ def test_ema_algorithm(dev):
     assert torch.equal(trainer.model.unet.master, avg) and torch.equal(trainer.optimizer.ema, live)
     ema.swap_params(trainer)
     assert torch.equal(trainer.model.unet.master, live)
+
+
+def test_sliced_optimizer_matches_single_launch(dev):
+    """AdamW issued in slices behind the gradient buckets (opt-in) == one launch: same gradients -> identical master,
+    moments, bf16 shadow and transposed shadow; and the trainer's sliced path runs on the side stream."""
+    from diffusion_amd.models.models import stable_diffusion_2
+    from diffusion_amd.optim import FusedAdamW
+    from diffusion_amd.trainer import Trainer
+    model = stable_diffusion_2(model_name='tiny', pretrained=False, precomputed_latents=True, fsdp=False, seed=3)
+    u = model.unet
+    opt = FusedAdamW(lr=1e-3, weight_decay=0.01, unet=u)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    u.grad.copy_(torch.randn(u.grad.numel(), device=dev, generator=gen) * 1e-2)
+    keep = [t.clone() for t in (u.master, u.exp_avg, u.exp_avg_sq, u.shadow, u.shadow_t)]
+    opt.step()
+    one = [t.clone() for t in (u.master, u.exp_avg, u.exp_avg_sq, u.shadow, u.shadow_t)]
+    for t, k in zip((u.master, u.exp_avg, u.exp_avg_sq, u.shadow, u.shadow_t), keep):
+        t.copy_(k)
+    u.opt_step -= 1
+    opt.begin_step()
+    n = u.master.numel()
+    cuts = [n, (n // 3 // 64) * 64 * 2, (n // 3 // 64) * 64, 64]
+    for hi, lo in zip(cuts[:-1], cuts[1:]):
+        opt.step_range(lo, hi)
+    opt.step()                                   # covers [0, 64) and refreshes the transposed shadow
+    for a, b in zip(one, (u.master, u.exp_avg, u.exp_avg_sq, u.shadow, u.shadow_t)):
+        assert torch.equal(a, b)
+    g = torch.Generator().manual_seed(5)
+    batch = {'image_latents': torch.randn(4, 4, 16, 16, generator=g).half().to(dev),
+             'caption_latents': torch.randn(4, 77, 128, generator=g).half().to(dev)}
+    tr = Trainer(model, train_dataloader=None, optimizers=opt, max_duration='2ba', device_train_microbatch_size=2)
+    tr.sliced_optimizer = True
+    tr.reducer.bucket = 200_000                  # several buckets even at tiny width
+    step0 = u.opt_step
+    loss = tr.train_batch(batch)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and len(tr.reducer.launched) > 2 and u.opt_step == step0 + 1
