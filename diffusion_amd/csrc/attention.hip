@@ -6,7 +6,7 @@
 //   statistics (running max, sum, LSE, delta) are per-lane scalars shared only with lane^32, and the
 //   P^T / dS^T accumulators are directly the B operands of the following products (O^T = V^T.P^T,
 //   dQ^T = K^T.dS^T) with no lane movement.  V^T / K^T reach the A operand through the transposed LDS
-//   read (ds_read_b64_tr_b16) of a [key][d] image whose 192-B row stride keeps the reads conflict-free.
+//   read (ds_read_b64_tr_b16) of a [key][d] image whose XOR-swizzled 128-B rows keep the reads conflict-free.
 //   dK/dV kernel is KEY-major: S = Q.K^T and dP = dO.V^T put the key on the lane; each wave keeps
 //   dK^T, dV^T of its 32 keys in accumulators while the workgroup sweeps the queries, so dK/dV need no
 //   cross-workgroup sum; P and dS accumulators are again the B operands of dV^T += dO^T.P and
@@ -31,7 +31,12 @@ struct AttnParams {
   float scale;  // softmax scale
 };
 
-constexpr int TR_LD = 192;  // bytes per row of a transposed-read image ([rows][64 bf16] + pad)
+// Transposed-read image: [rows][64 bf16] with unpadded 128-B rows; the 64-B half of a row is XOR-ed with bit 1 of the
+// row index.  A 32-lane half of ds_read_b64_tr_b16 touches 64 contiguous bytes of 4 consecutive rows: rows r, r+1 sit in
+// different 128-B halves of the 256-B bank span and rows r, r+2 in different 64-B halves of those, so the reads are
+// conflict-free without the 192-B padded rows used before (which kept the dQ kernel at two workgroups per CU).
+constexpr int TR_LD = 128;
+DEVINL int tr_off(int row, int bytecol) { return row * TR_LD + (bytecol ^ (((row >> 1) & 1) << 6)); }
 
 DEVINL int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -40,7 +45,7 @@ DEVINL bf16x8 tr_frag(const char* img, int row0, int col0, int lane) {
   // starting at row0) in the accumulator-as-operand k order: element j <-> image row
   // row0 + 8*(j>>2) + 4*(lane>>5) + (j&3).
   const int gg = lane >> 4, dgrp = gg & 1, hh = gg >> 1, qq = (lane >> 2) & 3, pp = lane & 3;
-  const char* a = img + (row0 + 4 * hh + qq) * TR_LD + (col0 + 16 * dgrp + 4 * pp) * 2;
+  const char* a = img + tr_off(row0 + 4 * hh + qq, (col0 + 16 * dgrp + 4 * pp) * 2);
   short4v t0 = lds_tr16_b64(a);
   short4v t1 = lds_tr16_b64(a + 8 * TR_LD);
   typedef __attribute__((ext_vector_type(8))) short short8v;
@@ -68,6 +73,37 @@ DEVINL float max3(float a, float b, float c) {
   return r;
 }
 
+// XCD-aware workgroup order.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own 4 MiB L2), so with
+// the plain (block, head, image) grid the blocks of ONE head land on eight different XCDs and every XCD streams the
+// K / V (or Q / dO) of ~24 heads at once - far more than its L2 - from the Infinity Cache / HBM (measured 6.1 TB/s
+// for the 10.7 GB a 4096-token forward launch reads: the kernels were bound by that, not by MFMA, VALU or occupancy).
+// Each XCD instead takes a contiguous run of (image, head, block) ids, block fastest: its ~96 resident workgroups
+// then share the operands of ~3 heads (3 MiB), which its L2 serves at ~2.5x the rate.
+DEVINL void xcd_block_id(int& blk, int& hd, int& b) {
+  const int nb = gridDim.x, nh = gridDim.y;
+  const int total = nb * nh * gridDim.z;
+  const int w = blockIdx.x + nb * (blockIdx.y + nh * blockIdx.z);  // dispatch order
+  const int q = total >> 3, r = total & 7;
+  const int xcd = w & 7, idx = w >> 3;
+  const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  blk = l % nb;
+  const int t = l / nb;
+  hd = t % nh;
+  b = t / nh;
+}
+
+// LDS-DMA (global_load_lds): 64 lanes x 16 B (or 4 B) land lane-linearly at a wave-uniform LDS address; no staging
+// registers, completion tracked by vmcnt.  Swizzles are therefore applied on the per-lane SOURCE address.
+__device__ __attribute__((aligned(256))) unsigned char g_attn_zero[256];
+DEVINL void dma16(const void* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+DEVINL void dma4(const void* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+
 DEVINL int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ------------------------------------------------------------------------------------------------
@@ -82,8 +118,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * FW_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q = blockIdx.x * 128 + wave * 32 + r;
+  int blk, hd, b;
+  xcd_block_id(blk, hd, b);
+  const int q = blk * 128 + wave * 32 + r;
   const bool qv = q < p.Nq;
 
   bf16x8 qf[4];
@@ -119,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int i = 0; i < 2; ++i) {
       int row = lrow + 32 * i;
       *reinterpret_cast<bf16x8*>(Ks + swz128(row, lchunk)) = rk[i];
-      *reinterpret_cast<bf16x8*>(Vs + row * TR_LD + lchunk * 16) = rv[i];
+      *reinterpret_cast<bf16x8*>(Vs + tr_off(row, lchunk * 16)) = rv[i];
     }
   };
 
@@ -219,12 +256,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------
 constexpr int DQ_STAGE = 2 * 64 * 128 + 64 * TR_LD;
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * DQ_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q = blockIdx.x * 128 + wave * 32 + r;
+  int blk, hd, b;
+  xcd_block_id(blk, hd, b);
+  const int q = blk * 128 + wave * 32 + r;
   const bool qv = q < p.Nq;
 
   bf16x8 qf[4], dof[4];
@@ -271,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
       int row = lrow + 32 * i;
       *reinterpret_cast<bf16x8*>(Ks + swz128(row, lchunk)) = rk[i];
       *reinterpret_cast<bf16x8*>(Vs + swz128(row, lchunk)) = rv[i];
-      *reinterpret_cast<bf16x8*>(Kt + row * TR_LD + lchunk * 16) = rk[i];
+      *reinterpret_cast<bf16x8*>(Kt + tr_off(row, lchunk * 16)) = rk[i];
     }
   };
 
@@ -346,14 +384,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 // backward, key-major: dK, dV.  Workgroup = 128 keys (4 waves x 32), sweeps all queries in 32-row tiles
 // (LDS double-buffered, one barrier per tile).
 // ------------------------------------------------------------------------------------------------
-constexpr int KV_STAGE = 2 * 32 * 128 + 2 * 32 * TR_LD + 2 * 32 * 4;
+constexpr int KV_STAGE = 4 * 32 * 128 + 2 * 32 * 4;  // Q, dO row images; Q, dO transposed-read images; L2, delta
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * KV_STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
+  // dynamic LDS on purpose: against a static __shared__ array the compiler treats every LDS-DMA as a possibly
+  // aliasing pending LDS write and puts s_waitcnt vmcnt(0) in front of the next ds_read, exposing the whole DMA latency
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 * KV_STAGE
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int key = blockIdx.x * 128 + wave * 32 + r;
+  int blk, hd, b;
+  xcd_block_id(blk, hd, b);
+  const int key = blk * 128 + wave * 32 + r;
   const bool kv = key < p.Nk;
 
   bf16x8 kf[4], vf[4];
@@ -367,54 +409,53 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
 
+  // Q / dO tiles (32 queries) reach LDS by DMA, three stages, issued TWO tiles ahead: a 32-query step lasts about one
+  // global-load latency, and with the register-staged prefetch consumed at the end of the same step the kernel spent
+  // 55 % of its wave-cycles waiting (skipping the loads made it 31 % faster).  Wave w fills rows 8w..8w+7 of the
+  // four images (row / transposed-read image of Q and of dO); wave 0 also fetches the 32 L2 and 32 delta values.
   const int nt = (p.Nq + 31) / 32;
-  const int lrow = tid >> 3, lchunk = tid & 7;  // 32 rows x 8 chunks = 256 threads
-  bf16x8 rq, rdo;
-  float rl = 0.f, rd = 0.f;
-  const bf16* qp = p.Q + ((long)b * p.Nq + lrow) * p.ldq + hd * 64 + lchunk * 8;
-  const bf16* dop = p.dO + ((long)b * p.Nq + lrow) * p.lddo + hd * 64 + lchunk * 8;
-  const float* l2p = p.L2 + ((long)b * p.H + hd) * p.Nq + tid;
-  const float* dlp = p.Delta + ((long)b * p.H + hd) * p.Nq + tid;
-  auto load = [&](int t) {
-    const bool ok = t * 32 + lrow < p.Nq;
-    rq = ok ? ld8(qp) : zero8();
-    rdo = ok ? ld8(dop) : zero8();
-    if (tid < 32) {
-      const bool ok2 = t * 32 + tid < p.Nq;
-      rl = ok2 ? -*l2p : 0.f;
-      rd = ok2 ? -*dlp : 0.f;  // negated: dS = P * (dP + (-delta)) is one packed add
+  const int drow = wave * 8 + (lane >> 3), pc = lane & 7;
+  const int lc_row = (pc ^ ((drow >> 1) & 7)) * 8;         // source element offset behind physical chunk pc: swz128
+  const int lc_tr = (pc ^ (((drow >> 1) & 1) << 2)) * 8;   //   ... and the transposed-read image (tr_off)
+  const bf16* qp = p.Q + ((long)b * p.Nq + drow) * p.ldq + hd * 64;
+  const bf16* dop = p.dO + ((long)b * p.Nq + drow) * p.lddo + hd * 64;
+  const float* statp = (lane < 32 ? p.L2 : p.Delta) + ((long)b * p.H + hd) * p.Nq + (lane & 31);
+  const char* zero = reinterpret_cast<const char*>(g_attn_zero);
+  auto dma = [&](int t, int st) {  // tiles are requested in order: the pointers advance by one tile per call
+    char* S = smem + st * KV_STAGE + wave * 1024;
+    const bool ok = t * 32 + drow < p.Nq;
+    dma16(ok ? (const void*)(qp + lc_row) : (const void*)zero, S);
+    dma16(ok ? (const void*)(dop + lc_row) : (const void*)zero, S + 4096);
+    dma16(ok ? (const void*)(qp + lc_tr) : (const void*)zero, S + 2 * 4096);
+    dma16(ok ? (const void*)(dop + lc_tr) : (const void*)zero, S + 3 * 4096);
+    if (wave == 0) {
+      const bool ok2 = t * 32 + (lane & 31) < p.Nq;
+      dma4(ok2 ? (const void*)statp : (const void*)zero, smem + st * KV_STAGE + 4 * 4096);
     }
     qp += 32 * p.ldq;
     dop += 32 * p.lddo;
-    l2p += 32;
-    dlp += 32;
+    statp += 32;
   };
-  auto store = [&](int st) {
-    char* Qs = smem + st * KV_STAGE;
-    char* Os = Qs + 32 * 128;
-    char* Qt = Qs + 2 * 32 * 128;
-    char* Ot = Qt + 32 * TR_LD;
-    float* Ls = reinterpret_cast<float*>(Ot + 32 * TR_LD);
-    *reinterpret_cast<bf16x8*>(Qs + swz128(lrow, lchunk)) = rq;
-    *reinterpret_cast<bf16x8*>(Os + swz128(lrow, lchunk)) = rdo;
-    *reinterpret_cast<bf16x8*>(Qt + lrow * TR_LD + lchunk * 16) = rq;
-    *reinterpret_cast<bf16x8*>(Ot + lrow * TR_LD + lchunk * 16) = rdo;
-    if (tid < 32) {
-      Ls[tid] = rl;
-      Ls[32 + tid] = rd;
-    }
+  // wait until at most the DMAs of the newest requested tile are outstanding (4 per wave, 5 on wave 0), then barrier
+  auto sync_tiles = [&](bool newest_in_flight) {
+    if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
 
-  load(0);
-  store(0);
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K / V fragments above: keep the counted waits below exact
+  dma(0, 0);
+  if (nt > 1) dma(1, 1);
+  sync_tiles(nt > 1);
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) load(t + 1);
-    const char* Qs = smem + (t & 1) * KV_STAGE;
-    const char* Os = Qs + 32 * 128;
-    const char* Qt = Qs + 2 * 32 * 128;
-    const char* Ot = Qt + 32 * TR_LD;
-    const float* Ls = reinterpret_cast<const float*>(Ot + 32 * TR_LD);
+    if (t + 2 < nt) dma(t + 2, (t + 2) % 3);  // its stage was last read in step t-1, released by that step's barrier
+    const char* Qs = smem + (t % 3) * KV_STAGE;
+    const char* Os = Qs + 4096;
+    const char* Qt = Qs + 2 * 4096;
+    const char* Ot = Qs + 3 * 4096;
+    const float* Ls = reinterpret_cast<const float*>(Qs + 4 * 4096);
     const float* Ds = Ls + 32;
     f32x16 s, dp;
 #pragma unroll
@@ -435,9 +476,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
       for (int e2 = 0; e2 < 2; ++e2) {
         const int i = rg * 2 + e2;  // pair index: accumulator registers 2i, 2i+1 = rows 2*e2, 2*e2+1 of this group
-        const f32x2 pv = exp2_2(__builtin_elementwise_fma(pair(s, i), sc2, f32x2{l4[2 * e2], l4[2 * e2 + 1]}));
+        const f32x2 pv = exp2_2(__builtin_elementwise_fma(pair(s, i), sc2, -f32x2{l4[2 * e2], l4[2 * e2 + 1]}));
         set_pair(pr, i, pv);
-        set_pair(s, i, pv * (pair(dp, i) + f32x2{d4[2 * e2], d4[2 * e2 + 1]}));
+        set_pair(s, i, pv * (pair(dp, i) - f32x2{d4[2 * e2], d4[2 * e2 + 1]}));
       }
     }
     // rows beyond Nq in the last tile: Q = dO = 0, L2 = delta = 0 -> p = 1, dS = 0, and dO^T.P adds 0.
@@ -454,8 +495,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt0, dsf[s2], dk0, 0, 0, 0);
       dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt1, dsf[s2], dk1, 0, 0, 0);
     }
-    if (t + 1 < nt) store((t + 1) & 1);
-    __syncthreads();
+    sync_tiles(t + 2 < nt);  // tile t+1 has landed; everyone is done reading stage t % 3
   }
   if (kv) {
     bf16* kp = p.dK + ((long)b * p.Nk + key) * p.lddk + hd * 64;
@@ -515,7 +555,7 @@ extern "C" int da_attn_bwd(const void* Q, long ldq, const void* K, long ldk, con
   p.scale = scale; p.sc = scale * 1.4426950408889634f;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, p);
   DA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Nk + 127) / 128, H, B), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Nk + 127) / 128, H, B), dim3(256), 3 * KV_STAGE, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

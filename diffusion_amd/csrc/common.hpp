@@ -104,3 +104,30 @@ static inline FastDiv make_fastdiv(unsigned int d) {
 DEVINL short4v lds_tr16_b64(const void* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(lds_addr));
 }
+
+// The same read issued through inline asm, for loops that also fill LDS by DMA (global_load_lds): in front of the
+// INTRINSIC the compiler's waitcnt pass assumes the pending DMA may alias and inserts s_waitcnt vmcnt(0), i.e. every
+// K-step waited for the next stage it had just requested.  The asm form is invisible to that pass; the caller orders
+// it with lds_wait<N>() (LDS reads return in order: N = reads that may still be outstanding), passing the registers
+// it is about to consume so that their users cannot be scheduled above the wait.
+DEVINL unsigned lds_offset(const void* p) {
+  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
+}
+DEVINL short4v lds_tr16_b64_asm(unsigned lds_byte_offset) {
+  short4v r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_byte_offset));
+  return r;
+}
+template <int N>
+DEVINL void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+template <typename T>
+DEVINL void reg_tie(T& r) {
+  asm volatile("" : "+v"(r));
+}
+template <int N, typename... T>
+DEVINL void lds_wait_for(T&... regs) {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  (reg_tie(regs), ...);
+}

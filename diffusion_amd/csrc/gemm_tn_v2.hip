@@ -260,42 +260,55 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // All transposed reads of a half-step are issued up front through the asm form (common.hpp: the intrinsic would
+  // make the compiler wait for the DMA just issued), then two counted waits: the dY fragments + the first half of the
+  // X fragments, 15 (+5 bias) MFMAs, the second half, 15 MFMAs.
+  const unsigned smem_off = lds_offset(smem);
   auto compute_half = [&](int stage, int ms) {
-    const char* Ab = smem + stage * T2_STAGE;
-    const char* Bb = Ab + T2_A_BYTES;
-    {
-      const int r0 = ms * 32 + 4 * g + q, r1 = r0 + 16;
-      bf16x8 a[5];
+    const unsigned Ab = smem_off + stage * T2_STAGE;
+    const unsigned Bb = Ab + T2_A_BYTES;
+    const int r0 = ms * 32 + 4 * g + q, r1 = r0 + 16;
+    short4v ta0[5], ta1[5], tb0[JT], tb1[JT];
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int ch = wa * 10 + i * 2 + (pp >> 1);
-        short4v t0 = lds_tr16_b64(Ab + r0 * T2_SA + ((ch ^ swA(r0)) << 4) + 8 * (pp & 1));
-        short4v t1 = lds_tr16_b64(Ab + r1 * T2_SA + ((ch ^ swA(r1)) << 4) + 8 * (pp & 1));
-        short8v v = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-        a[i] = __builtin_bit_cast(bf16x8, v);
+    for (int i = 0; i < 5; ++i) {
+      const int ch = wa * 10 + i * 2 + (pp >> 1);
+      ta0[i] = lds_tr16_b64_asm(Ab + r0 * T2_SA + ((ch ^ swA(r0)) << 4) + 8 * (pp & 1));
+      ta1[i] = lds_tr16_b64_asm(Ab + r1 * T2_SA + ((ch ^ swA(r1)) << 4) + 8 * (pp & 1));
+    }
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) {
+      const int ch = wb * (JT * 2) + jj * 2 + (pp >> 1);
+      tb0[jj] = lds_tr16_b64_asm(Bb + r0 * T2_SB + ((ch ^ swB<T2_BK>(r0)) << 4) + 8 * (pp & 1));
+      tb1[jj] = lds_tr16_b64_asm(Bb + r1 * T2_SB + ((ch ^ swB<T2_BK>(r1)) << 4) + 8 * (pp & 1));
+    }
+    static_assert(JT == 6, "counted waits below assume 6 X fragments per wave");
+    lds_wait_for<6>(ta0[0], ta1[0], ta0[1], ta1[1], ta0[2], ta1[2], ta0[3], ta1[3], ta0[4], ta1[4], tb0[0], tb1[0],
+                    tb0[1], tb1[1], tb0[2], tb1[2]);
+    bf16x8 a[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      short8v v = __builtin_shufflevector(ta0[i], ta1[i], 0, 1, 2, 3, 4, 5, 6, 7);
+      a[i] = __builtin_bit_cast(bf16x8, v);
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int jh = 0; jh < 2; ++jh) {
+      if (jh == 1) lds_wait_for<0>(tb0[3], tb1[3], tb0[4], tb1[4], tb0[5], tb1[5]);
+      bf16x8 bfr[JT / 2];
+#pragma unroll
+      for (int jj = 0; jj < JT / 2; ++jj) {
+        short8v v = __builtin_shufflevector(tb0[jh * (JT / 2) + jj], tb1[jh * (JT / 2) + jj], 0, 1, 2, 3, 4, 5, 6, 7);
+        bfr[jj] = __builtin_bit_cast(bf16x8, v);
       }
-      if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
-      }
+      for (int i = 0; i < 5; ++i)
 #pragma unroll
-      for (int jh = 0; jh < 2; ++jh) {  // B fragments in two halves: keeps the kernel under 256 VGPRs
-        bf16x8 b[JT / 2];
-#pragma unroll
-        for (int jj = 0; jj < JT / 2; ++jj) {
-          const int ch = wb * (JT * 2) + (jh * (JT / 2) + jj) * 2 + (pp >> 1);
-          short4v t0 = lds_tr16_b64(Bb + r0 * T2_SB + ((ch ^ swB<T2_BK>(r0)) << 4) + 8 * (pp & 1));
-          short4v t1 = lds_tr16_b64(Bb + r1 * T2_SB + ((ch ^ swB<T2_BK>(r1)) << 4) + 8 * (pp & 1));
-          short8v v = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-          b[jj] = __builtin_bit_cast(bf16x8, v);
-        }
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-          for (int jj = 0; jj < JT / 2; ++jj)
-            acc[i][jh * (JT / 2) + jj] =
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[jj], acc[i][jh * (JT / 2) + jj], 0, 0, 0);
-      }
+        for (int jj = 0; jj < JT / 2; ++jj)
+          acc[i][jh * (JT / 2) + jj] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bfr[jj], acc[i][jh * (JT / 2) + jj], 0, 0, 0);
     }
   };
 
@@ -305,8 +318,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     issue_fast(0, true);
     __syncthreads();
     for (int t = 0; t < nsteps; ++t) {  // one basic block: no branch around the issue
-      compute_half(t & 1, 0);
       issue_fast((t + 1) & 1, t + 1 < nsteps);
+      compute_half(t & 1, 0);
       compute_half(t & 1, 1);
       __syncthreads();
     }
