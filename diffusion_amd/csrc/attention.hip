@@ -53,6 +53,21 @@ DEVINL bf16x8 tr_frag(const char* img, int row0, int col0, int lane) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// tr_frag split in two for loops that also fill LDS by DMA: the two transposed reads are issued through the asm form
+// (common.hpp: against the intrinsic the compiler waits for every pending DMA), the caller waits with lds_wait_for<>
+// and then joins the halves.
+DEVINL void tr_frag_issue(unsigned img_off, int row0, int col0, int lane, short4v& t0, short4v& t1) {
+  const int gg = lane >> 4, dgrp = gg & 1, hh = gg >> 1, qq = (lane >> 2) & 3, pp = lane & 3;
+  const unsigned a = img_off + tr_off(row0 + 4 * hh + qq, (col0 + 16 * dgrp + 4 * pp) * 2);
+  t0 = lds_tr16_b64_asm(a);
+  t1 = lds_tr16_b64_asm(a + 8 * TR_LD);
+}
+DEVINL bf16x8 tr_frag_join(short4v t0, short4v t1) {
+  typedef __attribute__((ext_vector_type(8))) short short8v;
+  short8v v = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 DEVINL bf16x8 pack8(const f32x16& x, int s) {
   bf16x8 r;
 #pragma unroll
@@ -467,6 +482,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);     // S[q][key]
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[ks], dp, 0, 0, 0);   // dP[q][key]
     }
+    // the transposed dO / Q fragments do not depend on the softmax arithmetic below: request them now (asm form, so the
+    // compiler does not guard them with a wait for the tile DMA issued at the top of the step) and wait after it
+    short4v to0[2][2], to1[2][2], tq0[2][2], tq1[2][2];
+    const unsigned oto = lds_offset(Ot), qto = lds_offset(Qt);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      tr_frag_issue(oto, 16 * s2, 0, lane, to0[s2][0], to0[s2][1]);
+      tr_frag_issue(oto, 16 * s2, 32, lane, to1[s2][0], to1[s2][1]);
+      tr_frag_issue(qto, 16 * s2, 0, lane, tq0[s2][0], tq0[s2][1]);
+      tr_frag_issue(qto, 16 * s2, 32, lane, tq1[s2][0], tq1[s2][1]);
+    }
     f32x16 pr;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -484,16 +510,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
     // rows beyond Nq in the last tile: Q = dO = 0, L2 = delta = 0 -> p = 1, dS = 0, and dO^T.P adds 0.
     bf16x8 pf[2] = {pack8(pr, 0), pack8(pr, 1)};
     bf16x8 dsf[2] = {pack8(s, 0), pack8(s, 1)};
+    lds_wait_for<0>(to0[0][0], to0[0][1], to1[0][0], to1[0][1], tq0[0][0], tq0[0][1], tq1[0][0], tq1[0][1], to0[1][0],
+                    to0[1][1], to1[1][0], to1[1][1], tq0[1][0], tq0[1][1], tq1[1][0], tq1[1][1]);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 ot0 = tr_frag(Ot, 16 * s2, 0, lane);
-      bf16x8 ot1 = tr_frag(Ot, 16 * s2, 32, lane);
-      bf16x8 qt0 = tr_frag(Qt, 16 * s2, 0, lane);
-      bf16x8 qt1 = tr_frag(Qt, 16 * s2, 32, lane);
-      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot0, pf[s2], dv0, 0, 0, 0);
-      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot1, pf[s2], dv1, 0, 0, 0);
-      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt0, dsf[s2], dk0, 0, 0, 0);
-      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt1, dsf[s2], dk1, 0, 0, 0);
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(to0[s2][0], to0[s2][1]), pf[s2], dv0, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(to1[s2][0], to1[s2][1]), pf[s2], dv1, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tq0[s2][0], tq0[s2][1]), dsf[s2], dk0, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tq1[s2][0], tq1[s2][1]), dsf[s2], dk1, 0, 0, 0);
     }
     sync_tiles(t + 2 < nt);  // tile t+1 has landed; everyone is done reading stage t % 3
   }
