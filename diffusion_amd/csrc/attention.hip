@@ -272,8 +272,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 constexpr int DQ_STAGE = 2 * 64 * 128 + 64 * TR_LD;
 
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * DQ_STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * DQ_STAGE, dynamic: see attn_bwd_dkv_kernel
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
   int blk, hd, b;
   xcd_block_id(blk, hd, b);
@@ -301,39 +302,40 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
   for (int i = 0; i < 16; ++i) { d0[i] = 0.f; d1[i] = 0.f; }
 
   const int nt = (p.Nk + 63) / 64;
-  const int lrow = tid >> 3, lchunk = tid & 7;
-  bf16x8 rk[2], rv[2];
-  const bf16* kp = p.K + ((long)b * p.Nk + lrow) * p.ldk + hd * 64 + lchunk * 8;
-  const bf16* vp = p.V + ((long)b * p.Nk + lrow) * p.ldv + hd * 64 + lchunk * 8;
-  auto load = [&](int t) {
+  // K / V tiles (64 keys) reach LDS by DMA, one tile ahead into the stage the previous step released: no staging
+  // registers, no ds_write pass.  Wave w fills rows 8w..8w+7 and 32+8w..32+8w+7 of the three images (K and V row images,
+  // K transposed-read image).
+  const int drow = wave * 8 + (lane >> 3), pc = lane & 7;
+  const int lc_row = (pc ^ ((drow >> 1) & 7)) * 8;
+  const int lc_tr = (pc ^ (((drow >> 1) & 1) << 2)) * 8;
+  const bf16* kp = p.K + ((long)b * p.Nk + drow) * p.ldk + hd * 64;
+  const bf16* vp = p.V + ((long)b * p.Nk + drow) * p.ldv + hd * 64;
+  const char* zero = reinterpret_cast<const char*>(g_attn_zero);
+  auto dma = [&](int t, int st) {  // tiles are requested in order
+    char* S = smem + st * DQ_STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const bool ok = t * 64 + lrow + 32 * i < p.Nk;
-      rk[i] = ok ? ld8(kp + 32 * i * p.ldk) : zero8();
-      rv[i] = ok ? ld8(vp + 32 * i * p.ldv) : zero8();
+      const bool ok = t * 64 + drow + 32 * i < p.Nk;
+      const bf16* kr = kp + 32 * i * p.ldk;
+      const bf16* vr = vp + 32 * i * p.ldv;
+      dma16(ok ? (const void*)(kr + lc_row) : (const void*)zero, S + i * 4096);
+      dma16(ok ? (const void*)(vr + lc_row) : (const void*)zero, S + 8192 + i * 4096);
+      dma16(ok ? (const void*)(kr + lc_tr) : (const void*)zero, S + 16384 + i * 4096);
     }
     kp += 64 * p.ldk;
     vp += 64 * p.ldv;
   };
-  auto store = [&](int st) {
-    char* Ks = smem + st * DQ_STAGE;
-    char* Vs = Ks + 64 * 128;
-    char* Kt = Ks + 2 * 64 * 128;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int row = lrow + 32 * i;
-      *reinterpret_cast<bf16x8*>(Ks + swz128(row, lchunk)) = rk[i];
-      *reinterpret_cast<bf16x8*>(Vs + swz128(row, lchunk)) = rv[i];
-      *reinterpret_cast<bf16x8*>(Kt + tr_off(row, lchunk * 16)) = rk[i];
-    }
+  auto sync_tile = [&]() {  // the requested tile has landed; everyone is done reading the current one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
 
-  load(0);
-  store(0);
-  __syncthreads();
+  dma(0, 0);
+  sync_tile();
   auto step = [&](int t, auto tail_tag) {  // TAIL: compile-time split, see attn_fwd_kernel
     constexpr bool TAIL = decltype(tail_tag)::value;
-    if (t + 1 < nt) load(t + 1);
+    if (t + 1 < nt) dma(t + 1, (t + 1) & 1);
     const char* Ks = smem + (t & 1) * DQ_STAGE;
     const char* Vs = Ks + 64 * 128;
     const char* Kt = Ks + 2 * 64 * 128;
@@ -351,6 +353,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
       }
+      // K^T fragments for the dQ product: requested now (asm form), consumed after the arithmetic below
+      short4v tk0[2][2], tk1[2][2];
+      const unsigned kto = lds_offset(Kt);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        tr_frag_issue(kto, kb + 16 * s2, 0, lane, tk0[s2][0], tk0[s2][1]);
+        tr_frag_issue(kto, kb + 16 * s2, 32, lane, tk1[s2][0], tk1[s2][1]);
+      }
       {
         const f32x2 sc2 = {p.sc, p.sc}, nl2 = {nL2q, nL2q}, nde2 = {-delta, -delta};
 #pragma unroll
@@ -365,16 +375,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
           if (t * 64 + kb + acc_row(i, lane) >= p.Nk) s[i] = 0.f;
       }
       bf16x8 dsf[2] = {pack8(s, 0), pack8(s, 1)};
+      lds_wait_for<0>(tk0[0][0], tk0[0][1], tk1[0][0], tk1[0][1], tk0[1][0], tk0[1][1], tk1[1][0], tk1[1][1]);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 k0 = tr_frag(Kt, kb + 16 * s2, 0, lane);
-        bf16x8 k1 = tr_frag(Kt, kb + 16 * s2, 32, lane);
-        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, dsf[s2], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, dsf[s2], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tk0[s2][0], tk0[s2][1]), dsf[s2], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tk1[s2][0], tk1[s2][1]), dsf[s2], d1, 0, 0, 0);
       }
     }
-    if (t + 1 < nt) store((t + 1) & 1);
-    __syncthreads();
+    sync_tile();
   };
   const int nfull = p.Nk / 64;
   for (int t = 0; t < nfull; ++t) step(t, std::false_type{});
@@ -577,7 +585,7 @@ extern "C" int da_attn_bwd(const void* Q, long ldq, const void* K, long ldk, con
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
   p.scale = scale; p.sc = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 2 * DQ_STAGE, stream, p);
   DA_CHECK_LAUNCH();
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Nk + 127) / 128, H, B), dim3(256), 3 * KV_STAGE, stream, p);
   DA_CHECK_LAUNCH();
