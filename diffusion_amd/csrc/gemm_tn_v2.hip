@@ -275,15 +275,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
       ta0[i] = lds_tr16_b64_asm(Ab + r0 * T2_SA + ((ch ^ swA(r0)) << 4) + 8 * (pp & 1));
       ta1[i] = lds_tr16_b64_asm(Ab + r1 * T2_SA + ((ch ^ swA(r1)) << 4) + 8 * (pp & 1));
     }
-#pragma unroll
-    for (int jj = 0; jj < JT; ++jj) {
+    auto read_b = [&](int jj) {
       const int ch = wb * (JT * 2) + jj * 2 + (pp >> 1);
       tb0[jj] = lds_tr16_b64_asm(Bb + r0 * T2_SB + ((ch ^ swB<T2_BK>(r0)) << 4) + 8 * (pp & 1));
       tb1[jj] = lds_tr16_b64_asm(Bb + r1 * T2_SB + ((ch ^ swB<T2_BK>(r1)) << 4) + 8 * (pp & 1));
-    }
+    };
     static_assert(JT == 6, "counted waits below assume 6 X fragments per wave");
-    lds_wait_for<6>(ta0[0], ta1[0], ta0[1], ta1[1], ta0[2], ta1[2], ta0[3], ta1[3], ta0[4], ta1[4], tb0[0], tb1[0],
-                    tb0[1], tb1[1], tb0[2], tb1[2]);
+    // FAST has the registers to request all six X fragments at once; the generic path (more live gather state)
+    // requests the second three only after the first MFMA block, which keeps it free of spills
+#pragma unroll
+    for (int jj = 0; jj < (FAST ? JT : JT / 2); ++jj) read_b(jj);
+    if constexpr (FAST)
+      lds_wait_for<6>(ta0[0], ta1[0], ta0[1], ta1[1], ta0[2], ta1[2], ta0[3], ta1[3], ta0[4], ta1[4], tb0[0], tb1[0],
+                      tb0[1], tb1[1], tb0[2], tb1[2]);
+    else
+      lds_wait_for<0>(ta0[0], ta1[0], ta0[1], ta1[1], ta0[2], ta1[2], ta0[3], ta1[3], ta0[4], ta1[4], tb0[0], tb1[0],
+                      tb0[1], tb1[1], tb0[2], tb1[2]);
     bf16x8 a[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -296,7 +303,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     }
 #pragma unroll
     for (int jh = 0; jh < 2; ++jh) {
-      if (jh == 1) lds_wait_for<0>(tb0[3], tb1[3], tb0[4], tb1[4], tb0[5], tb1[5]);
+      if (jh == 1) {
+        if constexpr (!FAST) {
+#pragma unroll
+          for (int jj = JT / 2; jj < JT; ++jj) read_b(jj);
+        }
+        lds_wait_for<0>(tb0[3], tb1[3], tb0[4], tb1[4], tb0[5], tb1[5]);
+      }
       bf16x8 bfr[JT / 2];
 #pragma unroll
       for (int jj = 0; jj < JT / 2; ++jj) {
