@@ -99,6 +99,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   int mcur_f = m_begin;
   // ---- FAST-path descriptors (see the template comment); the generic ones follow
   unsigned fa_off[T2_AJ], fx_off[T2_BJ], fx_m0[T2_BJ], fx_m1[T2_BJ];
+  // source pixels per 64-pixel step and the (uniform) source element offset of step 0's first image row block
+  const int src_step = (int)((long)T2_MS * p.Hin * p.Win / HWo);
+  // the uniform base sits pad*(Win+1) source pixels below the block's first one, so every lane offset is >= 0
+  const long x_margin = (long)pad * (p.Win + 1);
+  const long x_base0 = ((long)(m_begin / T2_MS) * src_step - x_margin) * p.ldx;
   if constexpr (FAST) {
 #pragma unroll
     for (int j = 0; j < T2_AJ; ++j) {
@@ -118,11 +123,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
       const unsigned tap = kok ? fdiv((unsigned)kk, p.div_cin) : 0u;
       const int c = kok ? kk - (int)tap * p.Cin : 0;
       const int r = (int)tap / 3, s2 = (int)tap - 3 * r;  // ksize 1: tap == 0
-      // element offset from X + (pixel_of_step - pad*(Win+1)) * ldx : never negative
-      fx_off[j] = (unsigned)((row + r * p.Win + s2) * (int)p.ldx + c);
+      // Source element of this slot at step 0 by the general gather rule (stride 1 / 2, fused nearest-2x upsample),
+      // relative to X; later steps add a uniform stride (a 64-pixel step covers whole output rows, so the source
+      // advances by 64 * Hin*Win / (Hout*Wout) pixels).  Out-of-image taps are masked below.
       unsigned m0 = 0, m1 = 0;
+      {
+        const unsigned mm = (unsigned)(m_begin + row);
+        const unsigned bb = fdiv(mm, p.div_hw);
+        const unsigned rem = mm - bb * (unsigned)HWo;
+        const int oh = (int)fdiv(rem, p.div_w);
+        const int ow = (int)rem - oh * p.Wout;
+        // signed, NOT clamped (the slot is valid again at later steps and must keep a linear offset); >> floors
+        const int ih = (oh * gmul + r - pad) >> gshift, iw = (ow * gmul + s2 - pad) >> gshift;
+        fx_off[j] = (unsigned)(((long)bb * p.Hin * p.Win + (long)ih * p.Win + iw) * p.ldx + c - x_base0);
+      }
       if (kok) {
-        if (p.ksize == 1) {
+        if (p.ksize == 1 && p.mode == 0) {
           m0 = m1 = 0xffffffffu;
         } else {
           for (int ph = 0; ph < p.period; ++ph) {
@@ -130,7 +146,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
             const unsigned rem = mm - fdiv(mm, p.div_hw) * (unsigned)HWo;
             const int oh = (int)fdiv(rem, p.div_w);
             const int ow = (int)rem - oh * p.Wout;
-            const bool ok = (unsigned)(oh + r - 1) < (unsigned)p.Hin && (unsigned)(ow + s2 - 1) < (unsigned)p.Win;
+            const int th = oh * gmul + r - pad, tw = ow * gmul + s2 - pad;
+            const bool ok = (unsigned)th < (unsigned)hlim && (unsigned)tw < (unsigned)wlim;
             if (ph < 32) m0 |= (ok ? 1u : 0u) << ph;
             else m1 |= (ok ? 1u : 0u) << (ph - 32);
           }
@@ -148,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     const bf16* ab = p.dY + (long)mc * p.lddy;
 #pragma unroll
     for (int j = 0; j < T2_AJ; ++j) glds16_tn(ab + fa_off[j], Ab + (wave * T2_AJ + j) * 1024);
-    const bf16* xb = p.X + ((long)mc - pad * (p.Win + 1)) * p.ldx;
+    const bf16* xb = p.X + ((long)(mc / T2_MS) * src_step - x_margin) * p.ldx;
     const unsigned pb0 = (live && phase < 32) ? (1u << phase) : 0u;
     const unsigned pb1 = (live && phase >= 32) ? (1u << (phase - 32)) : 0u;
 #pragma unroll
@@ -479,7 +496,11 @@ int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X
   (void)variant;  // the 320x256 instantiation (160 accumulators) spills on gfx950 and lost to 320x192 everywhere
   const int HWo = Hout * Wout;
   p.period = 0;
-  if (mode == 0 && M % T2_MS == 0 && N >= 8) {
+  // FAST path: M a multiple of the 64-pixel step, a border pattern that repeats within 64 steps, and steps that cover
+  // whole output rows of the gather (so the source pixel advances uniformly): stride 1 always, stride 2 when
+  // 64 % Wout == 0, fused upsample when 64 % (2*Wout) == 0
+  const bool rows_ok = mode == 0 || (mode == 1 && T2_MS % Wout == 0) || (mode == 3 && T2_MS % (2 * Wout) == 0);
+  if (rows_ok && M % T2_MS == 0 && N >= 8 && ((long)T2_MS * Hin * Win) % HWo == 0) {
     if (HWo % T2_MS == 0 && HWo / T2_MS <= 64) p.period = HWo / T2_MS;
     else if (T2_MS % HWo == 0) p.period = 1;
   }

@@ -304,6 +304,31 @@ def test_wgrad_v2_forced(ops, dev, mode, variant):
         ops.set_option('gemm_tn_variant', 0)
 
 
+@pytest.mark.parametrize('mode', ['s1', 's2', 'up'])
+def test_wgrad_v2_fast_path_gathers(ops, dev, mode):
+    """Shapes that take the FAST wgrad path (M % 64 == 0, whole output rows per 64-pixel step): precomputed lane offsets
+    + uniform source stride + periodic border mask, for stride 1, stride 2 and the fused nearest-2x upsample."""
+    ops.set_option('gemm_tn_variant', 2)
+    try:
+        B, H, Wd, C, Co = 8, 16, 16, 64, 320
+        x = rnd(B, C, H, Wd, dev=dev, seed=1).to(BF)
+        w = torch.zeros(Co, C, 3, 3, device=dev, requires_grad=True)
+        if mode == 's1':
+            y = F.conv2d(x.float(), w, padding=1); g = ops.Geom.conv(B, H, Wd)
+        elif mode == 's2':
+            y = F.conv2d(x.float(), w, stride=2, padding=1); g = ops.Geom.down(B, H, Wd)
+        else:
+            y = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode='nearest'), w, padding=1); g = ops.Geom.up(B, H, Wd)
+        dy = rnd(*y.shape, dev=dev, seed=2).to(BF)
+        y.backward(dy.float())
+        dW = torch.full((Co, 9 * C), 1.0, device=dev); db = torch.zeros(Co, device=dev)
+        ops.gemm_tn_wgrad(nhwc(dy), nhwc(x), dW, g, dbias=db, scratch=torch.empty(256 * Co * 2, device=dev))
+        check(dW - 1.0, w_ohwi(w.grad), tol=2e-3, what=f'wgrad fast {mode}')
+        check(db, nhwc(dy).float().sum(0), tol=2e-3, what=f'wgrad fast dbias {mode}')
+    finally:
+        ops.set_option('gemm_tn_variant', 0)
+
+
 @pytest.mark.parametrize('variant', [2])
 def test_wgrad_v2_big(ops, dev, variant):
     ops.set_option('gemm_tn_variant', variant)
