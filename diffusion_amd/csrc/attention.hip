@@ -130,8 +130,9 @@ DEVINL int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * 
 constexpr int FW_STAGE = 64 * 128 + 64 * TR_LD;
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * FW_STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * FW_STAGE, dynamic: see attn_bwd_dkv_kernel
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
   int blk, hd, b;
   xcd_block_id(blk, hd, b);
@@ -149,40 +150,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   float m = -INFINITY, l = 0.f;
 
   const int nt = (p.Nk + 63) / 64;
-  const int lrow = tid >> 3, lchunk = tid & 7;
-  bf16x8 rk[2], rv[2];
-  // this thread's K / V source rows of tile 0; advanced by 64 rows per load (no per-tile address products)
-  const bf16* kp = p.K + ((long)b * p.Nk + lrow) * p.ldk + hd * 64 + lchunk * 8;
-  const bf16* vp = p.V + ((long)b * p.Nk + lrow) * p.ldv + hd * 64 + lchunk * 8;
-  auto load = [&](int t) {
+  // K / V tiles (64 keys) reach LDS by DMA, one tile ahead into the stage the previous step released: K as the row image,
+  // V as the transposed-read image.  Wave w fills rows 8w..8w+7 and 32+8w..32+8w+7 of both.
+  const int drow = wave * 8 + (lane >> 3), pc = lane & 7;
+  const int lc_row = (pc ^ ((drow >> 1) & 7)) * 8;
+  const int lc_tr = (pc ^ (((drow >> 1) & 1) << 2)) * 8;
+  const bf16* kp = p.K + ((long)b * p.Nk + drow) * p.ldk + hd * 64;
+  const bf16* vp = p.V + ((long)b * p.Nk + drow) * p.ldv + hd * 64;
+  const char* zero = reinterpret_cast<const char*>(g_attn_zero);
+  auto dma = [&](int t, int st) {  // tiles are requested in order
+    char* S = smem + st * FW_STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const bool ok = t * 64 + lrow + 32 * i < p.Nk;
-      rk[i] = ok ? ld8(kp + 32 * i * p.ldk) : zero8();
-      rv[i] = ok ? ld8(vp + 32 * i * p.ldv) : zero8();
+      const bool ok = t * 64 + drow + 32 * i < p.Nk;
+      dma16(ok ? (const void*)(kp + 32 * i * p.ldk + lc_row) : (const void*)zero, S + i * 4096);
+      dma16(ok ? (const void*)(vp + 32 * i * p.ldv + lc_tr) : (const void*)zero, S + 8192 + i * 4096);
     }
     kp += 64 * p.ldk;
     vp += 64 * p.ldv;
   };
-  auto store = [&](int st) {
-    char* Ks = smem + st * FW_STAGE;
-    char* Vs = Ks + 64 * 128;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int row = lrow + 32 * i;
-      *reinterpret_cast<bf16x8*>(Ks + swz128(row, lchunk)) = rk[i];
-      *reinterpret_cast<bf16x8*>(Vs + tr_off(row, lchunk * 16)) = rv[i];
-    }
+  auto sync_tile = [&]() {  // the requested tile has landed; everyone is done reading the current one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
 
-  load(0);
-  store(0);
-  __syncthreads();
+  dma(0, 0);
+  sync_tile();
   // One 64-key step.  TAIL (the ragged last tile) is a compile-time split: written as a run-time `if`, the key masking
   // was if-converted into every step (32 v_cmp + 32 v_cndmask + index adds, a third of the loop's VALU work).
   auto step = [&](int t, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
-    if (t + 1 < nt) load(t + 1);
+    if (t + 1 < nt) dma(t + 1, (t + 1) & 1);
     const char* Ks = smem + (t & 1) * FW_STAGE;
     const char* Vs = Ks + 64 * 128;
     f32x16 s0, s1;
@@ -194,6 +193,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Ks + swz128(32 + r, 2 * ks + h));
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
+    }
+    // V^T fragments for the P.V product: requested now (asm form), consumed after the softmax arithmetic
+    short4v tv[2][4][2];
+    const unsigned vto = lds_offset(Vs);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      tr_frag_issue(vto, 16 * s2, 0, lane, tv[s2][0][0], tv[s2][0][1]);
+      tr_frag_issue(vto, 16 * s2, 32, lane, tv[s2][1][0], tv[s2][1][1]);
+      tr_frag_issue(vto, 32 + 16 * s2, 0, lane, tv[s2][2][0], tv[s2][2][1]);
+      tr_frag_issue(vto, 32 + 16 * s2, 32, lane, tv[s2][3][0], tv[s2][3][1]);
     }
     if constexpr (TAIL) {
 #pragma unroll
@@ -231,18 +240,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       ls2 += e0 + e1;
     }
     l += ls2.x + ls2.y;
+    lds_wait_for<0>(tv[0][0][0], tv[0][0][1], tv[0][1][0], tv[0][1][1], tv[0][2][0], tv[0][2][1], tv[0][3][0], tv[0][3][1],
+                    tv[1][0][0], tv[1][0][1], tv[1][1][0], tv[1][1][1], tv[1][2][0], tv[1][2][1], tv[1][3][0], tv[1][3][1]);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       bf16x8 pa = pack8(s0, s2), pb = pack8(s1, s2);
-      bf16x8 va0 = tr_frag(Vs, 16 * s2, 0, lane), va1 = tr_frag(Vs, 16 * s2, 32, lane);
-      bf16x8 vb0 = tr_frag(Vs, 32 + 16 * s2, 0, lane), vb1 = tr_frag(Vs, 32 + 16 * s2, 32, lane);
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, pa, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, pa, o1, 0, 0, 0);
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb0, pb, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb1, pb, o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tv[s2][0][0], tv[s2][0][1]), pa, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tv[s2][1][0], tv[s2][1][1]), pa, o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tv[s2][2][0], tv[s2][2][1]), pb, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tv[s2][3][0], tv[s2][3][1]), pb, o1, 0, 0, 0);
     }
-    if (t + 1 < nt) store((t + 1) & 1);
-    __syncthreads();
+    sync_tile();
   };
   const int nfull = p.Nk / 64;
   for (int t = 0; t < nfull; ++t) step(t, std::false_type{});
@@ -564,7 +572,7 @@ extern "C" int da_attn_fwd(const void* Q, long ldq, const void* K, long ldk, con
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
   p.scale = scale; p.sc = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 2 * FW_STAGE, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
