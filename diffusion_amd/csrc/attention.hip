@@ -40,20 +40,9 @@ DEVINL int tr_off(int row, int bytecol) { return row * TR_LD + (bytecol ^ (((row
 
 DEVINL int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-DEVINL bf16x8 tr_frag(const char* img, int row0, int col0, int lane) {
-  // A operand of the 32x32x16 MFMA for (rows = columns col0..col0+31 of the image, k = 16 image rows
-  // starting at row0) in the accumulator-as-operand k order: element j <-> image row
-  // row0 + 8*(j>>2) + 4*(lane>>5) + (j&3).
-  const int gg = lane >> 4, dgrp = gg & 1, hh = gg >> 1, qq = (lane >> 2) & 3, pp = lane & 3;
-  const char* a = img + tr_off(row0 + 4 * hh + qq, (col0 + 16 * dgrp + 4 * pp) * 2);
-  short4v t0 = lds_tr16_b64(a);
-  short4v t1 = lds_tr16_b64(a + 8 * TR_LD);
-  typedef __attribute__((ext_vector_type(8))) short short8v;
-  short8v v = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-// tr_frag split in two for loops that also fill LDS by DMA: the two transposed reads are issued through the asm form
+// A operand of the 32x32x16 MFMA for (rows = columns col0..col0+31 of a transposed-read image, k = 16 image rows
+// starting at row0) in the accumulator-as-operand k order: element j <-> image row row0 + 8*(j>>2) + 4*(lane>>5) + (j&3).
+// Issued in two steps because every loop here also fills LDS by DMA: the two transposed reads go through the asm form
 // (common.hpp: against the intrinsic the compiler waits for every pending DMA), the caller waits with lds_wait_for<>
 // and then joins the halves.
 DEVINL void tr_frag_issue(unsigned img_off, int row0, int col0, int lane, short4v& t0, short4v& t1) {
@@ -123,7 +112,7 @@ DEVINL int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * 
 
 // ------------------------------------------------------------------------------------------------
 // forward.  Workgroup = 128 queries (4 waves x 32), 64-key tiles, LDS double-buffered (one barrier per tile),
-// next tile prefetched into registers while the current one is consumed.  Softmax per 64-key step:
+// next tile requested by LDS-DMA while the current one is consumed.  Softmax per 64-key step:
 // p = exp2(fma(s, sc, -m*sc)) on RAW scores (sc > 0 keeps the max order), rescale of O only when some lane's
 // running max moved (wave-uniform branch), key masking only on the ragged tail tile.
 // ------------------------------------------------------------------------------------------------

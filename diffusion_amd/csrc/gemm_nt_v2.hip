@@ -2,15 +2,17 @@
 //
 // Why: the 128x128x64 tile of v1 moves 32 KiB from L2 per 2.1 MFLOP (64 FLOP/B); at the bf16 MFMA peak that is
 // ~39 TB/s of L2->LDS traffic, more than the chip has, and v1 measures ~0.5 PFLOP/s on every large shape.
-// v2 uses a 256 x (128|160) x 64 tile (85 / 98 FLOP/B), 8 waves (4 along M x 2 along N, each 64 x (64|80) from
-// 4 x (4|5) v_mfma_f32_16x16x32_bf16 tiles), one workgroup per CU, and fills LDS with global_load_lds_dwordx4
-// (no staging registers, no ds_write pass).  BN = 160 makes every channel count of the SD-2 U-Net (multiples of
-// 320) tile exactly instead of wasting 17 % on N = 320.
+// v2 is one template over (MFMA tiles per wave, wave grid, K-step): the default large form is 256 x 320 x 64 with 16
+// waves (4 x 4, each 64 x 80 = 4 x 5 v_mfma_f32_16x16x32_bf16, <= 128 VGPRs, 4 waves per SIMD, 142 FLOP/B); 8-wave
+// forms 256 x (320|160|128) x 64 and a 4-wave 128 x 320 x 32 form exist for small / odd shapes and as references.
+// BN = 320 / 160 make every channel count of the SD-2 U-Net (multiples of 320) tile exactly.  One workgroup per CU,
+// LDS filled by global_load_lds_dwordx4 (no staging registers, no ds_write pass).
 // LDS-DMA writes lane-linearly (1 KiB = 8 rows x 128 B per wave instruction), so the XOR swizzle that keeps the
 // ds_read_b128 fragment reads conflict-free is applied on the per-lane SOURCE address; out-of-image taps and
 // out-of-range rows read a 128-B zero page instead of being predicated.
-// Two LDS stages; the loads of K-step t+1 are issued before the MFMAs of step t and retired by the
-// vmcnt(0)+barrier that ends the step.  Requires Cin % 64 == 0 (one tap per K-step).
+// Two LDS stages; the loads of K-step t+1 are issued during step t (at its start for 1x1 shapes, between its two MFMA
+// halves for 3x3) and retired by the vmcnt(0)+barrier that ends the step.  Requires Cin % 64 == 0 (one tap per K-step).
+// Epilogue variants: plain (bias / per-image row bias / residual), GEGLU forward, GEGLU backward, split-K slabs.
 #include "common.hpp"
 #include "diffusion_amd.h"
 

@@ -1,16 +1,17 @@
 // gemm_tn v2: large-tile LDS-DMA weight-gradient kernel (same contract as gemm_tn.hip).
 //     dW[n][tap*Cin + c]  +=  sum_m  dY[m][n] * X[pixel(m) + tap][c]
-// Tile: 320 (n) x 256 (k' = tap*Cin+c) fp32 accumulators per 512-thread workgroup (8 waves as 4 x 2, each
-// 80 x 128 = 5 x 8 v_mfma_f32_16x16x32_bf16 tiles), 64 pixels per stage, 2 LDS stages, one workgroup per CU
-// (142 FLOP per byte moved into LDS, as gemm_nt v2's 256x320 tile).  n = 320 tiles every channel count of the
-// SD-2 U-Net exactly.
+// Tile: 320 (n) x 192 (k' = tap*Cin+c) fp32 accumulators per 512-thread workgroup (8 waves as 4 x 2, each
+// 80 x 96 = 5 x 6 v_mfma_f32_16x16x32_bf16 tiles), 64 pixels per stage, 2 LDS stages, one workgroup per CU.  n = 320
+// tiles every channel count of the SD-2 U-Net exactly and 192 divides 9*Cin; the 320 x 256 form spills.
 // Both operands are staged exactly as they lie in HBM ([pixel][channel] rows) by global_load_lds_dwordx4 and
-// reach the MFMA k-major through ds_read_b64_tr_b16.  Conflict-free transposed reads need the 8 rows a 32-lane
-// half touches to sit in different bank octets; LDS-DMA cannot pad rows, so the 16-B chunk index is XOR-ed
-// on the SOURCE side:  X rows (512 B): chunk ^= 2*(row&7);  dY rows (640 B = 2.5 bank rows): chunk ^= 2*((row>>1)&3)
-// (the odd half bank-row offset of odd rows supplies the third bit).  Out-of-range rows / columns / padding
-// taps read a zero page.  Pixel range is split over workgroups; partials go to the fp32 gradient buffer with
-// global_atomic_add_f32.
+// reach the MFMA k-major through ds_read_b64_tr_b16 - issued through inline asm with counted lgkmcnt waits, because in
+// front of the intrinsic the compiler waits (vmcnt(0)) for the LDS-DMA the step has just requested.  Conflict-free
+// transposed reads need the 8 rows a 32-lane half touches to sit in different bank octets; LDS-DMA cannot pad rows, so
+// the 16-B chunk index is XOR-ed on the SOURCE side:  dY rows (640 B = 2.5 bank rows) and X rows (384 B):
+// chunk ^= 2*((row>>1)&3) (the odd half bank-row offset of odd rows supplies the third bit).  Out-of-range rows /
+// columns / padding taps read a zero page.  The pixel range is split over workgroups; split tiles store fp32 slabs
+// that tn_slab_reduce_kernel sums into dW (atomics only when the caller passes no workspace).
+// FAST path: see the kernel's template comment.
 #include "common.hpp"
 #include "diffusion_amd.h"
 
