@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 
 // ------------------------------------------------------------------------------------------------
 // backward, key-major: dK, dV.  Workgroup = 128 keys (4 waves x 32), sweeps all queries in 32-row tiles
-// (LDS double-buffered, one barrier per tile).
+// (three LDS stages filled by DMA two tiles ahead, one barrier per tile).
 // ------------------------------------------------------------------------------------------------
 constexpr int KV_STAGE = 4 * 32 * 128 + 2 * 32 * 4;  // Q, dO row images; Q, dO transposed-read images; L2, delta
 
