@@ -49,6 +49,15 @@ DEVINL int swz_key(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) &
 template <int BK>
 DEVINL int swz2(int row, int chunk) { return row * (BK * 2) + ((chunk ^ swz_key<BK>(row)) << 4); }
 
+// Workgroup barrier for the LDS strip exchange of the epilogues: waits for this wave's LDS traffic only.
+// __syncthreads() would also wait for vmcnt(0), i.e. complete at every strip the residual rows (and, in the fused GEGLU
+// backward, the saved activations) that are deliberately requested strips ahead.
+DEVINL void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 DEVINL void glds16(const void* gsrc, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           ew[((lane >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (lane & 15)] = acc[i][j][e];
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int pss = 0; pss < GPASSES; ++pss) {
         const int task = wn * 64 + lane + 64 * WN * pss;
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
           st8(p.G + (long)m * p.ldg + h0 + c8, og);
         }
       }
-      __syncthreads();  // single strip buffer: everyone is done reading before it is rewritten
+      lds_barrier();  // single strip buffer: everyone is done reading before it is rewritten
     }
     return;
   }
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           ew[((lane >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (lane & 15)] = acc[i][j][e];
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int pss = 0; pss < GPASSES; ++pss) {
         const int task = wn * 64 + lane + 64 * WN * pss;
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
           st8(op + p.inner, dg);
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
     return;
   }
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         ew[((lane >> 4) * 4 + e) * EPI_LD + wn * (16 * NT) + j * 16 + (lane & 15)] = acc[i][j][e];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int pss = 0; pss < PASSES; ++pss) {
       const int row = trow[pss], col8 = tcol[pss];
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
       }
     }
     if (has_r && i + RD < MT) fetch_r(i + RD, i % RD);
-    if (!EPI_DB) __syncthreads();  // single strip buffer: everyone is done reading before it is rewritten
+    if (!EPI_DB) lds_barrier();  // single strip buffer: everyone is done reading before it is rewritten
   }
 }
 
