@@ -566,10 +566,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* X, long ldx, co
 // LPR lanes share a row and each lane owns 5 vectors (40 channels), so a wave covers 64 / LPR rows at once and keeps
 // 5 (fwd) or 10-15 (bwd) 1-KiB loads in flight instead of one 640-B row; gamma / beta sit in LDS.  The one-row-per-
 // wave kernels above measured 2.8 (fwd) and 2.0 TB/s (bwd) at C = 320 against 5.6 TB/s for a streaming add.
+// sum over the LPR lanes that share a row, result in every lane.  Up to 16 lanes it is pure DPP (quad permutes, then
+// row_half_mirror and row_mirror pair each lane with one from the other half) instead of ds_bpermute round trips
+// through the LDS crossbar, which sat on the critical path of every row group; the 32-lane step keeps the shuffle.
+template <int CTRL>
+DEVINL float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 template <int LPR>
 DEVINL float group_sum(float v) {
-#pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v += dpp_f<0xB1>(v);                     // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);                     // quad_perm [2,3,0,1]
+  if (LPR >= 8) v += dpp_f<0x141>(v);      // row_half_mirror: lane i <-> 7-i of each 8
+  if (LPR >= 16) v += dpp_f<0x140>(v);     // row_mirror: lane i <-> 15-i of each 16
+  if (LPR >= 32) v += __shfl_xor(v, 16);
   return v;
 }
 
