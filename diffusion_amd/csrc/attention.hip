@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = max3(mx, s0[i], s1[i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, xor32(mx));
     if (__any(mx > m)) {
       const float mn = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f((m - mn) * p.sc);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int nfull = p.Nk / 64;
   for (int t = 0; t < nfull; ++t) step(t, std::false_type{});
   if (nfull < nt) step(nfull, std::true_type{});
-  const float lt = l + __shfl_xor(l, 32, 64);
+  const float lt = l + xor32(l);
   const float inv = 1.0f / lt;
   if (qv) {
     bf16* op = p.Out + ((long)b * p.Nq + q) * p.ldo + hd * 64;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) delta += bf2f(dof[ks][j]) * bf2f(of[j]);
   }
-  delta += __shfl_xor(delta, 32, 64);
+  delta += xor32(delta);
   const long statidx = ((long)b * p.H + hd) * p.Nq + q;
   const float nL2q = qv ? -p.L2[statidx] : 0.f;
   if (qv && h == 0) p.Delta[statidx] = delta;

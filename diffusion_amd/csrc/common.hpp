@@ -40,6 +40,16 @@ DEVINL bf16x8 zero8() {
   return z;
 }
 
+// Exchange with lane ^ 32 through v_permlane32_swap (gfx950): a VALU op instead of the ds_bpermute round trip behind
+// __shfl_xor(v, 32).  Returns the partner's value in every lane.
+DEVINL float xor32(float v) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  // r[0]: lanes 0-31 keep their value, lanes 32-63 receive lanes 0-31; r[1]: lanes 0-31 receive lanes 32-63
+  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 DEVINL float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
