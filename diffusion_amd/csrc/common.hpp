@@ -50,6 +50,22 @@ DEVINL float xor32(float v) {
   return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
 
+// value of lane ^ O for O = 8 (DPP row_ror:8 inside a 16-lane row), 16 (v_permlane16_swap), 32 (v_permlane32_swap)
+template <int O>
+DEVINL float lane_xor(float v) {
+  static_assert(O == 8 || O == 16 || O == 32, "lane_xor");
+  if constexpr (O == 8) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  } else if constexpr (O == 16) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
+  } else {
+    return xor32(v);
+  }
+}
+
 DEVINL float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

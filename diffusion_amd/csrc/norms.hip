@@ -579,7 +579,7 @@ DEVINL float group_sum(float v) {
   v += dpp_f<0x4E>(v);                     // quad_perm [2,3,0,1]
   if (LPR >= 8) v += dpp_f<0x141>(v);      // row_half_mirror: lane i <-> 7-i of each 8
   if (LPR >= 16) v += dpp_f<0x140>(v);     // row_mirror: lane i <-> 15-i of each 16
-  if (LPR >= 32) v += __shfl_xor(v, 16);
+  if (LPR >= 32) v += lane_xor<16>(v);
   return v;
 }
 
@@ -713,11 +713,16 @@ __global__ __launch_bounds__(256) void ln_bwd5_kernel(const bf16* X, long ldx, c
   for (int k = 0; k < 5; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) {
-        dg[k][e] += __shfl_xor(dg[k][e], o);
-        db[k][e] += __shfl_xor(db[k][e], o);
+      if constexpr (LPR <= 8) {
+        dg[k][e] += lane_xor<8>(dg[k][e]);
+        db[k][e] += lane_xor<8>(db[k][e]);
       }
+      if constexpr (LPR <= 16) {
+        dg[k][e] += lane_xor<16>(dg[k][e]);
+        db[k][e] += lane_xor<16>(db[k][e]);
+      }
+      dg[k][e] += lane_xor<32>(dg[k][e]);
+      db[k][e] += lane_xor<32>(db[k][e]);
       if (sub == 0) {
         red[(wave * C + 8 * (j + LPR * k) + e) * 2] = dg[k][e];
         red[(wave * C + 8 * (j + LPR * k) + e) * 2 + 1] = db[k][e];
