@@ -470,7 +470,8 @@ __global__ void splitk_finalize_kernel(GemmNT2Params p, const float* ws) {
     const long m = i / nvec;
     const int n = (int)(i - m * nvec) * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < p.splits; ++s) {
+#pragma unroll 4
+    for (int s = 0; s < p.splits; ++s) {  // unrolled: the slab loads of several splits are in flight together
       const float* src = ws + s * p.slab_stride + m * p.N + n;
       const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
