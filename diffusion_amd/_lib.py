@@ -21,6 +21,7 @@ SIGNATURES = {
     'da_gemm_nt_geglu': [_vp, _l, _vp, _vp, _l, _vp, _l, _fp, _i, _i, _i, _vp],
     'da_gemm_nt_geglu_bwd': [_vp, _l, _vp, _vp, _l, _vp, _l, _i, _i, _i, _vp],
     'da_gemm_tn_wgrad': [_vp, _l, _vp, _l, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _l, _vp],
+    'da_gemm_tn_variant_for': [_i, _i, _i, _i, _i, _i, _i, _i, _i],
     'da_attn_fwd': [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _fp, _i, _i, _i, _i, _f, _vp],
     'da_attn_bwd': [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _fp, _fp, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i,
                     _f, _vp],

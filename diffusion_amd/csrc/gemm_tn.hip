@@ -171,7 +171,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNParams p) {
 int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias,
                            int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, float* ws,
                            long ws_floats, hipStream_t stream);
+int da_gemm_tn_v2_fast_period(int M, int N, int Hin, int Win, int Hout, int Wout, int mode);
 int g_tn_variant = 0;  // 0 auto, 1 force v1 (128x128x32), 2 force v2 (320x192x64); da_set_option
+
+static bool tn_takes_v2(int M, int N, int Kt) {
+  const bool big = (M >= 4096) && (N >= 160) && (Kt >= 256);
+  return g_tn_variant == 2 || g_tn_variant == 3 || (g_tn_variant == 0 && big);
+}
+
+extern "C" int da_gemm_tn_variant_for(int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode) {
+  if (!tn_takes_v2(M, N, ksize * ksize * Cin)) return 1;
+  return da_gemm_tn_v2_fast_period(M, N, Hin, Win, Hout, Wout, mode) ? 3 : 2;
+}
 
 extern "C" int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias,
                                 float* scratch, int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize,
@@ -185,8 +196,7 @@ extern "C" int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long l
   if (Hout <= 0 || Wout <= 0 || (M % (Hout * Wout))) return DA_ERR_SHAPE;
   {
     const int Kt = ksize * ksize * Cin;
-    const bool big = (M >= 4096) && (N >= 160) && (Kt >= 256);
-    if (g_tn_variant == 2 || g_tn_variant == 3 || (g_tn_variant == 0 && big))
+    if (tn_takes_v2(M, N, Kt))
       return da_gemm_tn_v2_dispatch(g_tn_variant == 2 ? 2 : 3, dY, lddy, X, ldx, dW, dbias, M, N, Cin, Hin, Win, Hout, Wout, ksize, mode,
                                     split_ws, split_ws ? split_ws_floats : 0, stream);
   }

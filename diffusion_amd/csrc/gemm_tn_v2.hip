@@ -484,6 +484,20 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
 
 }  // namespace
 
+// FAST path of the 320x192x64 wgrad kernel: M a multiple of the 64-pixel step, a border pattern that repeats within
+// 64 steps, and steps that cover whole output rows of the gather (so the source pixel advances uniformly): stride 1
+// always, stride 2 when 64 % Wout == 0, fused upsample when 64 % (2*Wout) == 0.  Returns the period of the border mask
+// in steps (0: not eligible, the generic gather runs).
+int da_gemm_tn_v2_fast_period(int M, int N, int Hin, int Win, int Hout, int Wout, int mode) {
+  const int HWo = Hout * Wout;
+  const bool rows_ok = mode == 0 || (mode == 1 && T2_MS % Wout == 0) || (mode == 3 && T2_MS % (2 * Wout) == 0);
+  if (rows_ok && M % T2_MS == 0 && N >= 8 && ((long)T2_MS * Hin * Win) % HWo == 0) {
+    if (HWo % T2_MS == 0 && HWo / T2_MS <= 64) return HWo / T2_MS;
+    if (T2_MS % HWo == 0) return 1;
+  }
+  return 0;
+}
+
 // Called by da_gemm_tn_wgrad (gemm_tn.hip) after argument validation.
 int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias,
                            int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, float* ws,
@@ -499,15 +513,6 @@ int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X
   p.tiles_n = p.tiles_k = p.splits = p.m_per_split = 0;
   p.slab = nullptr;
   (void)variant;  // the 320x256 instantiation (160 accumulators) spills on gfx950 and lost to 320x192 everywhere
-  const int HWo = Hout * Wout;
-  p.period = 0;
-  // FAST path: M a multiple of the 64-pixel step, a border pattern that repeats within 64 steps, and steps that cover
-  // whole output rows of the gather (so the source pixel advances uniformly): stride 1 always, stride 2 when
-  // 64 % Wout == 0, fused upsample when 64 % (2*Wout) == 0
-  const bool rows_ok = mode == 0 || (mode == 1 && T2_MS % Wout == 0) || (mode == 3 && T2_MS % (2 * Wout) == 0);
-  if (rows_ok && M % T2_MS == 0 && N >= 8 && ((long)T2_MS * Hin * Win) % HWo == 0) {
-    if (HWo % T2_MS == 0 && HWo / T2_MS <= 64) p.period = HWo / T2_MS;
-    else if (T2_MS % HWo == 0) p.period = 1;
-  }
+  p.period = da_gemm_tn_v2_fast_period(M, N, Hin, Win, Hout, Wout, mode);
   return p.period ? launch_tn2<192, true>(p, ws, ws_floats, stream) : launch_tn2<192, false>(p, ws, ws_floats, stream);
 }

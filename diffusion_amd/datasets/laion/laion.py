@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence, Union
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader, Dataset
+from torch.utils.data import DataLoader, Dataset, DistributedSampler, RandomSampler, SequentialSampler
 
 
 class SyntheticLAIONDataset(Dataset):
@@ -55,17 +55,27 @@ class MDSLatentDataset(Dataset):
         self.mds = MDSDirectory(directory)
         self.image_size, self.tokenizer, self.caption_drop_prob = image_size, tokenizer, caption_drop_prob
         self.col = f'latents_{image_size}'
+        self.skipped = 0
+
+    MAX_SKIP = 4096
 
     def __len__(self):
         return len(self.mds)
 
     def __getitem__(self, index):
-        smp = self.mds.get(index, columns=('caption', 'caption_latents', self.col))
         s = self.image_size // 8
-        lat = np.frombuffer(smp[self.col], dtype=np.float16)
-        if lat.size != 4 * s * s:
-            # the writer stores b'' when the source image is smaller than the resolution (precompute_latents.py:303-306)
-            raise IndexError(f'sample {index} has no {self.col}')
+        n = len(self.mds)
+        # the writer stores b'' when the source image is smaller than the resolution (precompute_latents.py:303-306):
+        # such a sample cannot be trained on at this resolution - take the next one that can (deterministic in index)
+        for probe in range(self.MAX_SKIP):
+            smp = self.mds.get((index + probe) % n, columns=('caption', 'caption_latents', self.col))
+            lat = np.frombuffer(smp[self.col], dtype=np.float16)
+            if lat.size == 4 * s * s:
+                break
+            self.skipped += 1
+        else:
+            raise RuntimeError(f'{self.MAX_SKIP} consecutive samples from index {index} have no {self.col}: '
+                               f'this MDS directory holds no latents for {self.image_size} px')
         out = {'caption_latents': torch.from_numpy(np.frombuffer(smp['caption_latents'], dtype=np.float16).copy()).reshape(77, -1),
                'image_latents': torch.from_numpy(lat.copy()).reshape(4, s, s)}
         caption = '' if torch.rand(1) < self.caption_drop_prob else smp.get('caption', '')
@@ -127,25 +137,71 @@ def build_streaming_laion_dataloader(
     num_canonical_nodes: Optional[int] = None,
     **dataloader_kwargs,
 ):
-    if isinstance(remote, str) and isinstance(local, str):
-        remote, local = [remote], [local]
-    elif isinstance(remote, Sequence) and isinstance(local, Sequence) and len(remote) != len(local):
+    remote, local = _as_list(remote), _as_list(local)
+    if remote and local and len(remote) != len(local):
         raise ValueError(f'remote and local Sequences must be the same length, got lengths {len(remote)} and {len(local)}')
+    if remote and not local:
+        raise ValueError('a remote without a local cache directory cannot be read here: mosaicml-streaming (download-on-'
+                         'miss) is not available; point `local` at a directory that already holds the shards')
     text_dim = dataloader_kwargs.pop('text_dim', 1024)
     with_images = dataloader_kwargs.pop('synthetic_images', False)
-    dirs = [d for d in (local or []) if d and os.path.isdir(d)]
-    if dirs:
+    seed = int(dataloader_kwargs.pop('seed', 17))
+    if local:
+        missing = [d for d in local if not os.path.isdir(d)]
+        if missing:  # never fall through to synthetic noise because of a mistyped path
+            raise FileNotFoundError(f'local dataset director{"ies" if len(missing) > 1 else "y"} not found: {missing}')
         from ...models.text import build_tokenizer
         tok = build_tokenizer(tokenizer_name_or_path if os.path.isdir(str(tokenizer_name_or_path)) else None)
         parts = [MDSLatentDataset(d, resize_size, tok, caption_drop_prob) if os.path.exists(os.path.join(d, 'index.json'))
-                 else LocalLatentShards(d, resize_size) for d in dirs]
+                 else LocalLatentShards(d, resize_size) for d in local]
         dataset = torch.utils.data.ConcatDataset(parts)
-    else:
+    else:  # both remote and local empty (the shipped YAML): seeded synthetic data of the same shapes
         dataset = SyntheticLAIONDataset(image_size=resize_size, caption_drop_prob=caption_drop_prob, text_dim=text_dim,
-                                        with_images=with_images)
+                                        with_images=with_images, seed=seed)
     if num_samples is not None:
         dataset = torch.utils.data.Subset(dataset, range(num_samples))
     if dataloader_kwargs.get('num_workers', 0) == 0:
         dataloader_kwargs.pop('prefetch_factor', None)
         dataloader_kwargs.pop('persistent_workers', None)
-    return DataLoader(dataset=dataset, batch_size=batch_size, sampler=None, drop_last=drop_last, **dataloader_kwargs)
+    # The reference gets shuffling and the per-rank partition from StreamingDataset (laion.py:167-180: shuffle=...,
+    # batch_size=..., num_canonical_nodes=...) with train.py:40 dividing the batch by the world size.  Here: a
+    # rank-strided partition of a per-epoch seeded permutation (torch DistributedSampler), so the ranks of a data-
+    # parallel job read disjoint, jointly exhaustive samples; single process: a seeded RandomSampler.
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if world > 1:
+        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed,
+                                     drop_last=drop_last)
+    elif shuffle:
+        sampler = RandomSampler(dataset, generator=torch.Generator().manual_seed(seed))
+    else:
+        sampler = SequentialSampler(dataset)
+    return EpochDataLoader(dataset=dataset, batch_size=batch_size, sampler=sampler, drop_last=drop_last, **dataloader_kwargs)
+
+
+def _as_list(x) -> List[str]:
+    """None / '' -> [], 'path' -> ['path'], sequences -> list without empty entries."""
+    if x is None:
+        return []
+    if isinstance(x, (str, os.PathLike)):
+        return [str(x)] if str(x) else []
+    return [str(d) for d in x if d]
+
+
+class EpochDataLoader(DataLoader):
+    """DataLoader that advances its sampler's epoch each time a new iterator is made (a DistributedSampler reshuffles
+    only when told the epoch); ``set_epoch`` lets a resumed run continue the sequence."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._next_epoch = 0
+
+    def set_epoch(self, epoch: int):
+        self._next_epoch = int(epoch)
+
+    def __iter__(self):
+        if hasattr(self.sampler, 'set_epoch'):
+            self.sampler.set_epoch(self._next_epoch)
+        self._next_epoch += 1
+        return super().__iter__()

@@ -75,6 +75,10 @@ int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long ldx, float* 
                      int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, float* split_ws,
                      long split_ws_floats, da_stream_t stream);
 
+/* which kernel da_gemm_tn_wgrad dispatches to (test / profiling label): 1 = gemm_tn_kernel (128x128x32, register-staged),
+ * 2 = gemm_tn2_kernel<192, generic gather>, 3 = gemm_tn2_kernel<192, FAST> (uniform source stride + periodic border mask) */
+int da_gemm_tn_variant_for(int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode);
+
 /* softmax(Q K^T * scale) V for head_dim 64, heads at column offsets h*64 of Q/K/V/O; L2[B][H][Nq] receives the
  * per-row log2-sum-exp.  Replaces xformers memory_efficient_attention (models.py:109-111) / diffusers
  * attention for attn1 (self) and attn2 (cross, Nk = 77). */

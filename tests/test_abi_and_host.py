@@ -175,6 +175,25 @@ def test_metric_shim_and_dataloader_local(tmp_path):
     assert bt['image_latents'].shape == (3, 4, 32, 32) and bt['caption_latents'].shape == (3, 77, 1024)
     with pytest.raises(ValueError):
         build_streaming_laion_dataloader(remote=['a', 'b'], local=['a'], batch_size=1)
+    # `local` alone as a plain string (the shipped YAML leaves `remote:` blank) reads that directory ...
+    dl = build_streaming_laion_dataloader(remote=None, local=str(d), batch_size=2, resize_size=256, shuffle=False)
+    assert len(dl.dataset) == 6 and torch.equal(next(iter(dl))['image_latents'], bt['image_latents'][:2])
+    # ... and a mistyped / missing directory is an error, never a silent fall-back to synthetic noise
+    with pytest.raises(FileNotFoundError):
+        build_streaming_laion_dataloader(remote=None, local=str(d) + '-typo', batch_size=2)
+    with pytest.raises(FileNotFoundError):
+        build_streaming_laion_dataloader(remote='', local=[str(d), str(tmp_path / 'nope')], batch_size=2)
+    with pytest.raises(ValueError):
+        build_streaming_laion_dataloader(remote='s3://bucket/laion', local=None, batch_size=2)
+    # both empty -> the seeded synthetic dataset; shuffle is honoured and changes from epoch to epoch
+    syn = build_streaming_laion_dataloader(remote=None, local='', batch_size=4, num_samples=32, shuffle=True, seed=5)
+    e0 = torch.cat([b['image_latents'][:, 0, 0, 0] for b in syn])
+    e1 = torch.cat([b['image_latents'][:, 0, 0, 0] for b in syn])
+    seq = build_streaming_laion_dataloader(remote=None, local=None, batch_size=4, num_samples=32, shuffle=False, seed=5)
+    s0 = torch.cat([b['image_latents'][:, 0, 0, 0] for b in seq])
+    assert not torch.equal(e0, s0) and not torch.equal(e0, e1)
+    assert torch.equal(e0.sort().values, s0.sort().values) and torch.equal(e1.sort().values, s0.sort().values)
+    assert torch.equal(s0, torch.cat([b['image_latents'][:, 0, 0, 0] for b in seq]))
 
 
 def test_mds_reader_roundtrip(tmp_path):
@@ -207,6 +226,32 @@ def test_mds_reader_roundtrip(tmp_path):
     assert b['caption_latents'].shape == (3, 77, 1024) and b['captions'].shape == (3, 77)
     ref = torch.from_numpy(np.frombuffer(samples[1]['latents_256'], np.float16).copy()).reshape(4, 32, 32)
     assert torch.equal(b['image_latents'][1], ref)
-    dl512 = build_streaming_laion_dataloader(remote=d, local=d, batch_size=1, resize_size=512, num_workers=0)
-    with pytest.raises(IndexError):
+    # no sample holds 512-px latents: a clear error, not an IndexError from inside a worker
+    dl512 = build_streaming_laion_dataloader(remote=d, local=d, batch_size=1, resize_size=512, num_workers=0, shuffle=False)
+    with pytest.raises(RuntimeError, match='have no latents_512'):
         next(iter(dl512))
+
+
+def test_mds_samples_without_latents_are_skipped(tmp_path):
+    """b'' in latents_512 (image smaller than 512 px, precompute_latents.py:303-306) must not abort the epoch: the loader
+    substitutes the next sample that has latents."""
+    import numpy as np
+    from diffusion_amd.datasets.mds import write_mds
+    from diffusion_amd.datasets.laion.laion import build_streaming_laion_dataloader
+    rng = np.random.default_rng(1)
+    cols = {'caption': 'str', 'caption_latents': 'bytes', 'latents_256': 'bytes', 'latents_512': 'bytes'}
+    have = [True, False, False, True, True, False, True, False]
+    samples = [{'caption': f'c{i}', 'caption_latents': rng.standard_normal((77, 1024)).astype(np.float16).tobytes(),
+                'latents_256': rng.standard_normal((4, 32, 32)).astype(np.float16).tobytes(),
+                'latents_512': rng.standard_normal((4, 64, 64)).astype(np.float16).tobytes() if h else b''}
+               for i, h in enumerate(have)]
+    d = str(tmp_path / 'mds')
+    write_mds(d, cols, samples, samples_per_shard=3)
+    dl = build_streaming_laion_dataloader(remote=None, local=d, batch_size=4, resize_size=512, shuffle=False, num_workers=0)
+    got = torch.cat([b['image_latents'] for b in dl])
+    assert got.shape == (8, 4, 64, 64)
+    nxt = [0, 3, 3, 3, 4, 6, 6, 0]   # index -> next index (cyclic) holding 512-px latents
+    for i, j in enumerate(nxt):
+        ref = torch.from_numpy(np.frombuffer(samples[j]['latents_512'], np.float16).copy()).reshape(4, 64, 64)
+        assert torch.equal(got[i], ref), (i, j)
+    assert dl.dataset.datasets[0].skipped == 5

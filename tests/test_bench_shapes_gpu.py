@@ -1,0 +1,257 @@
+"""Per-kernel parity AT THE BENCHMARK'S SHAPES, through automatic dispatch.
+
+bench.py's step (BASELINE.json configs[1]: batch 256, latents 4x32x32; configs[3]/[4]: 64^2 and 96^2 latents) spends its
+time in kernel variants that small test shapes never select: the 16-wave 256x320 implicit-GEMM form of da_gemm_nt
+(variant 12, with its GEGLU / split-K epilogues), the FAST path of the 320x192x64 wgrad kernel, and the attention
+kernels at 1,024 - 9,216 tokens.  Each test below calls the C ABI with dispatch left on "auto", asserts which variant
+the dispatcher picks, and compares with a plain fp32 PyTorch computation of the same op on the same bf16-rounded inputs
+(the 3x3 convolution reference is nine shifted fp32 matmuls, so it does not depend on MIOpen).
+
+Tolerances: bf16 outputs carry 2^-9 relative rounding -> rel-L2 <= 4e-3 over the whole tensor AND over every 256-row
+block (a single wrong tile of a 262,144-row output would vanish in a whole-tensor norm); fp32 outputs (wgrad, reduced
+over up to 262,144 pixels in a different order) <= 2e-3 as in tests/test_kernels_gpu.py; attention as there (6e-3
+forward, 1.2e-2 backward)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope='module')
+def ops(dev):
+    from diffusion_amd import ops as o
+    old = o.SPLITK_WS
+    if o.SPLITK_WS is None:  # what UNetHIP allocates: 128 MiB of fp32 slabs
+        o.SPLITK_WS = torch.empty(32 * 1024 * 1024, device=dev, dtype=torch.float32)
+    yield o
+    o.SPLITK_WS = old
+
+
+def rnd(*shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return torch.randn(*shape, generator=g, device=dev) * scale
+
+
+def rel_l2(a, r):
+    a, r = a.float(), r.float()
+    return ((a - r).norm() / (r.norm() + 1e-12)).item()
+
+
+def check_blocks(a, r, tol=4e-3, rows=256, what=''):
+    assert a.shape == r.shape, (what, a.shape, r.shape)
+    a, r = a.float(), r.float()
+    assert torch.isfinite(a).all(), what
+    e = rel_l2(a, r)
+    assert e < tol, f'{what}: rel-L2 {e:.3e} >= {tol}'
+    M = a.shape[0] - a.shape[0] % rows
+    if M:
+        d = (a[:M] - r[:M]).reshape(M // rows, -1).norm(dim=1)
+        n = r[:M].reshape(M // rows, -1).norm(dim=1) + 1e-12
+        worst = (d / n).max().item()
+        assert worst < 2 * tol, f'{what}: worst {rows}-row block rel-L2 {worst:.3e}'
+
+
+def nt_variant(ops, M, N, K, Cin):
+    from diffusion_amd import _lib
+    return _lib.load().da_gemm_nt_variant_for(M, N, K, Cin, ops.SPLITK_WS.numel())
+
+
+def tn_variant(g, M, N, Cin):
+    from diffusion_amd import _lib
+    return _lib.load().da_gemm_tn_variant_for(M, N, Cin, g.Hin, g.Win, g.Hout, g.Wout, g.ksize, g.mode)
+
+
+def conv3x3_ref(x, w, B, H, W):
+    """x: [B*H*W, C] (any float dtype), w: [N, 9*C] OHWI -> fp32 [B*H*W, N] by nine shifted matmuls."""
+    C, N = x.shape[1], w.shape[0]
+    xp = F.pad(x.float().reshape(B, H, W, C), (0, 0, 1, 1, 1, 1))
+    w4 = w.float().reshape(N, 3, 3, C)
+    out = torch.zeros(B * H * W, N, device=x.device)
+    for r in range(3):
+        for s in range(3):
+            out += xp[:, r:r + H, s:s + W, :].reshape(-1, C) @ w4[:, r, s, :].t()
+    return out
+
+
+def wgrad3x3_ref(dy, x, B, H, W):
+    C, N = x.shape[1], dy.shape[1]
+    xp = F.pad(x.float().reshape(B, H, W, C), (0, 0, 1, 1, 1, 1))
+    out = torch.empty(N, 3, 3, C, device=x.device)
+    dyt = dy.float().t().contiguous()
+    for r in range(3):
+        for s in range(3):
+            out[:, r, s, :] = dyt @ xp[:, r:r + H, s:s + W, :].reshape(-1, C)
+    return out.reshape(N, 9 * C)
+
+
+# (B, H, Cin, Cout): the conv shapes that dominate the 256-px step - batch 256
+CONVS = [(256, 32, 320, 320), (256, 8, 1280, 1280), (256, 16, 640, 640)]
+
+
+@pytest.mark.parametrize('B,H,Cin,Cout', CONVS)
+def test_conv3x3_fwd_dgrad_wgrad_at_bench_shape(ops, dev, B, H, Cin, Cout):
+    M = B * H * H
+    g = ops.Geom.conv(B, H, H)
+    x = rnd(M, Cin, dev=dev, seed=1).to(BF)
+    w = rnd(Cout, 9 * Cin, dev=dev, seed=2, scale=(9 * Cin)**-0.5).to(BF)
+    bias = rnd(Cout, dev=dev, seed=3)
+    rb = rnd(B, Cout, dev=dev, seed=4).to(BF)
+    res = rnd(M, Cout, dev=dev, seed=5).to(BF)
+    assert nt_variant(ops, M, Cout, 9 * Cin, Cin) == 12
+    # forward with the resnet epilogues: conv1 (bias + per-image timestep row) and conv2 (bias + residual)
+    ref = conv3x3_ref(x, w, B, H, H)
+    out = torch.empty(M, Cout, device=dev, dtype=BF)
+    ops.gemm_nt(x, w, out, g, bias=bias, rowbias=rb)
+    check_blocks(out, ref + bias + rb.float().repeat_interleave(H * H, 0), what='conv fwd bias+rowbias')
+    ops.gemm_nt(x, w, out, g, bias=bias, residual=res)
+    check_blocks(out, ref + bias + res.float(), what='conv fwd bias+residual')
+    del ref
+    # dgrad: same kernel on the transposed / flipped weight shadow
+    dy = rnd(M, Cout, dev=dev, seed=6).to(BF)
+    wt = torch.empty(Cin, 9 * Cout, device=dev, dtype=BF)
+    ops.transpose_weight(w, wt, Cout, 9, Cin)
+    assert nt_variant(ops, M, Cin, 9 * Cout, Cout) == 12
+    dx = torch.empty(M, Cin, device=dev, dtype=BF)
+    ops.gemm_nt(dy, wt, dx, g)
+    w_flip = w.float().reshape(Cout, 3, 3, Cin).flip(1, 2).permute(3, 1, 2, 0).reshape(Cin, 9 * Cout)
+    check_blocks(dx, conv3x3_ref(dy, w_flip, B, H, H), what='conv dgrad')
+    # wgrad (FAST path) with the fused bias gradient, accumulating onto existing content
+    assert tn_variant(g, M, Cout, Cin) == 3
+    dW = torch.full((Cout, 9 * Cin), 0.25, device=dev)
+    db = torch.full((Cout,), 1.0, device=dev)
+    ops.gemm_tn_wgrad(dy, x, dW, g, dbias=db, scratch=torch.empty(256 * Cout * 2, device=dev))
+    check_blocks(dW - 0.25, wgrad3x3_ref(dy, x, B, H, H), tol=2e-3, rows=64, what='conv wgrad')
+    check_blocks((db - 1.0)[None], dy.float().sum(0)[None], tol=2e-3, what='conv wgrad dbias')
+
+
+def test_conv_on_concat_view_at_bench_shape(ops, dev):
+    """up_blocks.1.resnets.0.conv1: input is the [M, 1280+1280] concat buffer whose halves were written by different
+    producers; output goes into a column slice of the next concat buffer (strided C)."""
+    B, H, Ca, Cb, Cout = 256, 8, 1280, 1280, 1280
+    M = B * H * H
+    cat = torch.empty(M, Ca + Cb, device=dev, dtype=BF)
+    cat[:, :Ca] = rnd(M, Ca, dev=dev, seed=1).to(BF)
+    cat[:, Ca:] = rnd(M, Cb, dev=dev, seed=2).to(BF)
+    w = rnd(Cout, 9 * (Ca + Cb), dev=dev, seed=3, scale=(9 * (Ca + Cb))**-0.5).to(BF)
+    bias = rnd(Cout, dev=dev, seed=4)
+    nxt = torch.zeros(M, Cout + 640, device=dev, dtype=BF)
+    assert nt_variant(ops, M, Cout, 9 * (Ca + Cb), Ca + Cb) == 12
+    ops.gemm_nt(cat, w, nxt[:, :Cout], ops.Geom.conv(B, H, H), bias=bias)
+    check_blocks(nxt[:, :Cout], conv3x3_ref(cat, w, B, H, H) + bias, what='conv 2560->1280 concat')
+    assert (nxt[:, Cout:] == 0).all()
+    # the backward splits the dgrad by views: dX of the whole buffer, consumers read its column halves
+    dy = rnd(M, Cout, dev=dev, seed=5).to(BF)
+    assert tn_variant(ops.Geom.conv(B, H, H), M, Cout, Ca + Cb) == 3
+    dW = torch.zeros(Cout, 9 * (Ca + Cb), device=dev)
+    ops.gemm_tn_wgrad(dy, cat, dW, ops.Geom.conv(B, H, H))
+    check_blocks(dW, wgrad3x3_ref(dy, cat, B, H, H), tol=2e-3, rows=64, what='conv 2560->1280 wgrad')
+
+
+@pytest.mark.parametrize('N,K', [(320, 320), (960, 320), (320, 1280)])
+def test_linear_at_bench_shape(ops, dev, N, K):
+    """Transformer linears of the 32x32 level at batch 256: M = 262,144 tokens (to_out / fused QKV / ff.net.2)."""
+    M = 262144
+    A = rnd(M, K, dev=dev, seed=1).to(BF)
+    W = rnd(N, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
+    bias = rnd(N, dev=dev, seed=3)
+    R = rnd(M, N, dev=dev, seed=4).to(BF)
+    assert nt_variant(ops, M, N, K, K) == 12
+    out = torch.empty(M, N, device=dev, dtype=BF)
+    ops.gemm_nt(A, W, out, ops.Geom.linear(M), bias=bias, residual=R)
+    check_blocks(out, A.float() @ W.float().t() + bias + R.float(), what='linear bias+residual')
+    g = ops.Geom.linear(M)
+    assert tn_variant(g, M, N, K) == 3
+    dW = torch.zeros(N, K, device=dev)
+    db = torch.zeros(N, device=dev)
+    ops.gemm_tn_wgrad(R, A, dW, g, dbias=db, scratch=torch.empty(256 * N * 2, device=dev))
+    check_blocks(dW, R.float().t() @ A.float(), tol=2e-3, rows=64, what='linear wgrad')
+    check_blocks(db[None], R.float().sum(0)[None], tol=2e-3, what='linear dbias')
+
+
+def test_geglu_fused_at_bench_shape(ops, dev):
+    M, K, inner = 262144, 320, 1280
+    A = rnd(M, K, dev=dev, seed=1).to(BF)
+    W = rnd(2 * inner, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
+    bias = rnd(2 * inner, dev=dev, seed=3)
+    f = torch.empty(M, 2 * inner, device=dev, dtype=BF)
+    g = torch.empty(M, inner, device=dev, dtype=BF)
+    ops.gemm_nt_geglu(A, W, f, g, bias)
+    h = A.float() @ W.float().t() + bias
+    check_blocks(f, h, what='geglu pre-activation')
+    check_blocks(g, h[:, :inner] * F.gelu(h[:, inner:]), what='geglu gated')
+    del h
+    # backward: dgrad of ff.net.2 gated against the saved pre-activation
+    dy = rnd(M, K, dev=dev, seed=4).to(BF)
+    wt = rnd(inner, K, dev=dev, seed=5, scale=inner**-0.5).to(BF)
+    df = torch.empty(M, 2 * inner, device=dev, dtype=BF)
+    ops.gemm_nt_geglu_bwd(dy, wt, f, df)
+    dg = dy.float() @ wt.float().t()
+    a, gate = f[:, :inner].float(), f[:, inner:].float()
+    cdf = 0.5 * (1.0 + torch.erf(gate * 2**-0.5))
+    pdf = torch.exp(-0.5 * gate * gate) * (2 * math.pi)**-0.5
+    check_blocks(df[:, :inner], dg * gate * cdf, what='geglu bwd d(value)')
+    check_blocks(df[:, inner:], dg * a * (cdf + gate * pdf), what='geglu bwd d(gate)')
+
+
+def _attn_ref(q, k, v, H, scale):
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    sp = lambda z, n: z.reshape(B, n, H, 64).permute(0, 2, 1, 3)
+    w = torch.softmax(sp(q, Nq) @ sp(k, Nk).transpose(-1, -2) * scale, dim=-1)
+    return (w @ sp(v, Nk)).permute(0, 2, 1, 3).reshape(B, Nq, C)
+
+
+# self-attention of the 64^2 / 96^2 / 32^2 latents' first level, and cross-attention against 77 text tokens
+@pytest.mark.parametrize('B,H,Nq,Nk', [(2, 5, 4096, 4096), (1, 5, 9216, 9216), (8, 5, 1024, 1024), (4, 5, 4096, 77),
+                                       (4, 10, 1024, 1024), (2, 5, 9216, 77)])
+def test_attention_at_bench_shape(ops, dev, B, H, Nq, Nk):
+    C = H * 64
+    scale = 0.125
+    # heads addressed inside the fused [M, 3C] / [B*77, 2C] buffers as UNetHIP lays them out
+    if Nq == Nk:
+        qkv = rnd(B * Nq, 3 * C, dev=dev, seed=1).to(BF)
+        q2, k2, v2 = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    else:
+        q2 = rnd(B * Nq, C, dev=dev, seed=1).to(BF)
+        kv = rnd(B * Nk, 2 * C, dev=dev, seed=2).to(BF)
+        k2, v2 = kv[:, :C], kv[:, C:]
+    do = rnd(B * Nq, C, dev=dev, seed=4).to(BF)
+    qf, kf, vf = (t.float().reshape(B, n, C).requires_grad_(True) for t, n in ((q2, Nq), (k2, Nk), (v2, Nk)))
+    ref = _attn_ref(qf, kf, vf, H, scale)
+    ref.backward(do.float().reshape(B, Nq, C))
+    ref = ref.detach()
+    O = torch.empty(B * Nq, C, device=dev, dtype=BF)
+    L2 = torch.empty(B * H * Nq, device=dev)
+    ops.attn_fwd(q2, k2, v2, O, L2, B, H, Nq, Nk, scale)
+    check_blocks(O, ref.reshape(B * Nq, C), tol=6e-3, what='attn fwd')
+    dQ = torch.empty_like(O)
+    dKV = torch.empty(B * Nk, 2 * C, device=dev, dtype=BF)
+    Delta = torch.empty_like(L2)
+    ops.attn_bwd(q2, k2, v2, O, do, L2, Delta, dQ, dKV[:, :C], dKV[:, C:], B, H, Nq, Nk, scale)
+    check_blocks(dQ, qf.grad.reshape(B * Nq, C), tol=1.2e-2, what='attn dQ')
+    rows = 256 if Nk >= 256 else Nk
+    check_blocks(dKV[:, :C], kf.grad.reshape(B * Nk, C), tol=1.2e-2, rows=rows, what='attn dK')
+    check_blocks(dKV[:, C:], vf.grad.reshape(B * Nk, C), tol=1.2e-2, rows=rows, what='attn dV')
+
+
+@pytest.mark.parametrize('B,HW,C', [(256, 1024, 320), (256, 64, 2560), (64, 4096, 320)])
+def test_groupnorm_at_bench_shape(ops, dev, B, HW, C):
+    G, eps = 32, 1e-5
+    x = rnd(B * HW, C, dev=dev, seed=1, scale=2.0).to(BF) + 0.5
+    gamma = rnd(C, dev=dev, seed=2) * 0.2 + 1.0
+    beta = rnd(C, dev=dev, seed=3) * 0.2
+    y = torch.empty_like(x)
+    st = torch.empty(B * G * 2, device=dev)
+    ss = torch.empty(B * C * 2, device=dev)
+    scratch = torch.empty(ops.norm_scratch_floats(B, HW, C), device=dev)
+    ops.groupnorm_fwd(x, y, gamma, beta, st, ss, scratch, B, HW, C, G, eps, 1)
+    xf = x.float().reshape(B, HW, G, C // G)
+    mean = xf.mean(dim=(1, 3), keepdim=True)
+    var = xf.var(dim=(1, 3), unbiased=False, keepdim=True)
+    n = ((xf - mean) * torch.rsqrt(var + eps)).reshape(B * HW, C) * gamma + beta
+    check_blocks(y, F.silu(n), what='groupnorm+silu fwd')

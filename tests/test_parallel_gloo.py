@@ -59,6 +59,55 @@ def test_bucketed_allreduce_gloo_world2():
     assert res[0][2] >= 3  # several buckets were launched before the final flush
 
 
+def _loader_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from diffusion_amd.datasets.laion.laion import build_streaming_laion_dataloader
+    out = {}
+    for shuffle in (False, True):
+        dl = build_streaming_laion_dataloader(remote=None, local=None, batch_size=5, num_samples=40, shuffle=shuffle,
+                                              drop_last=True, seed=9)
+        epochs = []
+        for _ in range(2):
+            idx = []
+            for b in dl:
+                assert b['image_latents'].shape == (5, 4, 32, 32)
+                idx += [float(v) for v in b['image_latents'][:, 0, 0, 0]]   # a per-sample fingerprint
+            epochs.append(idx)
+        out[shuffle] = epochs
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dataloader_partitions_samples_by_rank_gloo_world2():
+    """reference: StreamingDataset partitions samples over ranks (laion.py:167-180) and train.py:40 divides the batch by
+    the world size.  Two ranks must read disjoint, jointly exhaustive samples; shuffle reorders them per epoch."""
+    from diffusion_amd.datasets.laion.laion import SyntheticLAIONDataset
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loader_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ds = SyntheticLAIONDataset(num_samples=40, seed=9)
+    every = sorted(float(ds[i]['image_latents'][0, 0, 0]) for i in range(40))
+    for shuffle in (False, True):
+        for ep in range(2):
+            a, b = res[0][shuffle][ep], res[1][shuffle][ep]
+            assert len(a) == len(b) == 20
+            assert not (set(a) & set(b)), 'ranks read the same samples'
+            assert sorted(a + b) == every, 'ranks together must cover the dataset'
+    assert res[0][False][0] == res[0][False][1]          # unshuffled: same order every epoch
+    assert res[0][True][0] != res[0][True][1]            # shuffled: a new permutation each epoch
+    assert res[0][True][0] != res[0][False][0]
+
+
 def test_reducer_single_process_is_noop():
     from diffusion_amd.parallel import BucketedAllReducer
     flat = torch.arange(1000, dtype=torch.float32)
