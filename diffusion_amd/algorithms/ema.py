@@ -43,11 +43,22 @@ class EMA(Callback):
         """Called by the trainer right before ``optimizer.step()`` of batch ``trainer.batch_idx`` (0-based)."""
         opt = trainer.optimizer
         done = trainer.batch_idx + 1
-        if not self.ema_started and done > self._start_batch(trainer):
+        if (not self.ema_started and done > self._start_batch(trainer)) or (self.ema_started and opt.ema is None):
             opt.ema = trainer.model.unet.master.clone()  # start the average from the current weights
             opt.ema_smoothing = self.smoothing
             self.ema_started = True
         opt.ema_update_this_step = self.ema_started and (done % self.update_interval == 0)
+
+    # checkpoint state (reference: ema.py:280-336 serialises the shadow parameters and its bookkeeping; here the shadow
+    # itself lives in the optimizer's flat buffers and is saved there)
+    def state_dict(self):
+        return {'smoothing': self.smoothing, 'ema_started': self.ema_started, 'ema_weights_active': self.ema_weights_active,
+                'update_interval': self.update_interval}
+
+    def load_state_dict(self, sd):
+        self.ema_started = bool(sd['ema_started'])
+        self.ema_weights_active = bool(sd.get('ema_weights_active', False))
+        self.smoothing = float(sd.get('smoothing', self.smoothing))
 
     def swap_params(self, trainer):
         """Exchange live and averaged weights (call again to swap back)."""

@@ -28,6 +28,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     if (e__ != hipSuccess) return DA_ERR_LAUNCH;            \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: remember it per device ordinal, not per process, so a
+// process that drives several GPUs raises the limit on each of them (one bit per device in *done_mask).
+static inline int da_ensure_dyn_smem(const void* fn, int bytes, unsigned long long* done_mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DA_ERR_LAUNCH;
+  if (*done_mask & (1ull << dev)) return DA_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return DA_ERR_LAUNCH;
+  *done_mask |= 1ull << dev;
+  return DA_OK;
+}
+
 DEVINL float bf2f(bf16 x) { return (float)x; }
 DEVINL bf16 f2bf(float x) { return (bf16)x; }
 

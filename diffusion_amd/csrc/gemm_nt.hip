@@ -329,13 +329,8 @@ extern "C" int da_gemm_nt(const void* A, long lda, const void* W, void* C, long 
   p.ksize = ksize; p.mode = mode; p.out_fp32 = out_fp32; p.alpha = alpha;
   p.tiles_m = (M + BM - 1) / BM;
   p.tiles_n = (N + BN - 1) / BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) !=
-        hipSuccess)
-      return DA_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (da_ensure_dyn_smem((const void*)gemm_nt_kernel, SMEM_BYTES, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), SMEM_BYTES, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;

@@ -514,13 +514,8 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
   static_assert(SMEM - BN * 4 >= WM * 16 * (BN + 4) * 4, "epilogue strips fit in the stage buffers");
   p.tiles_m = (p.M + V2_BM - 1) / V2_BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
-        hipSuccess)
-      return DA_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (da_ensure_dyn_smem((const void*)gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
   const int nk_total = p.K / V2_BK;
   p.splits = splits > 1 ? splits : 1;
   p.ksteps_per_split = (nk_total + p.splits - 1) / p.splits;
@@ -551,13 +546,8 @@ int launch_v2_geglu(GemmNT2Params p, hipStream_t stream) {
   p.tiles_n = GM == 1 ? (p.inner + BN / 2 - 1) / (BN / 2) : (p.inner + BN - 1) / BN;
   p.splits = 1;
   p.ksteps_per_split = p.K / 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt2_kernel<4, 5, 4, 4, 64, false, GM, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
-      return DA_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (da_ensure_dyn_smem((const void*)gemm_nt2_kernel<4, 5, 4, 4, 64, false, GM, true>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
   hipLaunchKernelGGL((gemm_nt2_kernel<4, 5, 4, 4, 64, false, GM, true>), dim3(p.tiles_m * p.tiles_n), dim3(1024), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;

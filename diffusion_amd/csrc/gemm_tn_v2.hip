@@ -461,13 +461,8 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
   mps = ((mps + T2_MS - 1) / T2_MS) * T2_MS;
   p.splits = (p.M + mps - 1) / mps;
   p.m_per_split = mps;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_tn2_kernel<BK, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
-        hipSuccess)
-      return DA_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (da_ensure_dyn_smem((const void*)gemm_tn2_kernel<BK, FAST>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
   p.slab = nullptr;
   if (p.splits > 1 && ws && (long)tiles * p.splits * T2_BN * BK <= ws_floats && (p.Kt & 3) == 0) p.slab = ws;
   hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST>), dim3(tiles * p.splits), dim3(512), SMEM, stream, p);

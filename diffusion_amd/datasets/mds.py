@@ -6,10 +6,15 @@ precomputed latents live in (written by /root/reference scripts/precompute_laten
 version 2, no compression - the reference writes ``compression=None``, precompute_latents.py:275):
   directory/index.json : {"version": 2, "shards": [{"column_names", "column_encodings", "column_sizes" (null = variable),
                           "samples", "raw_data": {"basename"}, "compression": null, "format": "mds", ...}]}
-  shard file           : uint32 num_samples | uint32 offsets[num_samples+1] (from file start) | sample blobs
+  shard file           : uint32 num_samples | uint32 offsets[num_samples+1] (ABSOLUTE, from file start) |
+                         config blob (the writer repeats the shard's column table as JSON here; the offsets skip it) |
+                         sample blobs
   sample blob          : uint32 size for every variable-size column (in column order) | column payloads in order
+  column order         : the writer sorts the columns by NAME; readers must follow index.json's ``column_names``
   encodings used here  : bytes, str (utf-8), int8..int64 / uint8..uint64 / float16..float64 (numpy scalars), int (int64)
-NOT validated against files produced by the real package (none available offline): round-trip tested only."""
+No file produced by the real package is available offline; besides the round trip through ``write_mds`` the reader is
+tested on a shard assembled byte by byte from this layout with ``struct`` (tests/test_abi_and_host.py), including the
+config blob, name-sorted columns and the b'' latents of images below the resolution."""
 from __future__ import annotations
 
 import json
@@ -105,10 +110,14 @@ class MDSDirectory:
 
 
 def write_mds(directory: str, columns: Dict[str, str], samples: List[dict], samples_per_shard: int = 1 << 30):
-    """Minimal writer of the same layout (tests / local conversion of latents); no compression, no hashes."""
+    """Minimal writer of the same layout (tests / local conversion of latents): columns sorted by name and the config
+    blob in front of the samples, as ``streaming.MDSWriter`` lays a shard out; no compression, no hashes."""
     os.makedirs(directory, exist_ok=True)
-    names, encs = list(columns), list(columns.values())
+    names = sorted(columns)
+    encs = [columns[n] for n in names]
     sizes = [_fixed_size(e) for e in encs]
+    config = json.dumps({'column_encodings': encs, 'column_names': names, 'column_sizes': sizes, 'compression': None,
+                         'format': 'mds', 'hashes': [], 'size_limit': None, 'version': 2}, sort_keys=True).encode('utf-8')
     shards = []
     for si, start in enumerate(range(0, len(samples), samples_per_shard)):
         chunk = samples[start:start + samples_per_shard]
@@ -118,11 +127,11 @@ def write_mds(directory: str, columns: Dict[str, str], samples: List[dict], samp
             head = b''.join(np.uint32(len(p)).tobytes() for p, s in zip(payload, sizes) if s is None)
             blobs.append(head + b''.join(payload))
         n = len(chunk)
-        header = 4 + 4 * (n + 1)
+        header = 4 + 4 * (n + 1) + len(config)
         offs = np.cumsum([header] + [len(b) for b in blobs]).astype(np.uint32)
         base = f'shard.{si:05d}.mds'
         with open(os.path.join(directory, base), 'wb') as f:
-            f.write(np.uint32(n).tobytes() + offs.tobytes() + b''.join(blobs))
+            f.write(np.uint32(n).tobytes() + offs.tobytes() + config + b''.join(blobs))
         shards.append({'column_encodings': encs, 'column_names': names, 'column_sizes': sizes, 'compression': None,
                        'format': 'mds', 'hashes': [], 'raw_data': {'basename': base, 'bytes': int(offs[-1]), 'hashes': {}},
                        'samples': n, 'size_limit': None, 'version': 2, 'zip_data': None})

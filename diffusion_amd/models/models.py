@@ -11,6 +11,7 @@
 from __future__ import annotations
 
 import os
+import warnings
 from typing import List, Optional
 
 import torch
@@ -37,6 +38,31 @@ def _load_local_unet_weights(unet: UNetHIP, directory: str):
             unet.load_state_dict(load_file(path))
             return
     raise FileNotFoundError(f'no safetensors U-Net weights under {directory}/unet')
+
+
+# diffusers < 0.17 checkpoints (the published SD-2 VAE files among them) name the mid-block attention projections
+# query / key / value / proj_attn; later versions to_q / to_k / to_v / to_out.0.  Accept both.
+_VAE_ATTN_RENAMES = (('.query.', '.to_q.'), ('.key.', '.to_k.'), ('.value.', '.to_v.'), ('.proj_attn.', '.to_out.0.'))
+
+
+def load_local_vae_weights(vae, directory: str):
+    """Strictly load ``<directory>/vae/*.safetensors`` into the PyTorch-ROCm AutoencoderKL (reference: models.py:80-85
+    always loads pretrained VAE weights)."""
+    from safetensors.torch import load_file
+    for fn in ('diffusion_pytorch_model.safetensors', 'model.safetensors'):
+        path = os.path.join(directory, 'vae', fn)
+        if os.path.exists(path):
+            sd = {}
+            for k, v in load_file(path).items():
+                if '.attentions.' in k:
+                    for old, new in _VAE_ATTN_RENAMES:
+                        k = k.replace(old, new)
+                    if v.dim() == 4 and v.shape[-2:] == (1, 1) and ('.to_' in k):
+                        v = v[:, :, 0, 0]  # very old checkpoints store the projections as 1x1 convolutions
+                sd[k] = v
+            vae.load_state_dict(sd, strict=True)
+            return path
+    raise FileNotFoundError(f'no safetensors VAE weights under {directory}/vae')
 
 
 def stable_diffusion_2(
@@ -88,9 +114,20 @@ def stable_diffusion_2(
     if build_encoders:
         from .vae import AutoencoderKL
         dtype = torch.float16 if encode_latents_in_fp16 else torch.float32
-        vae = AutoencoderKL().to('cuda', dtype)
-        text_encoder = build_text_encoder(os.path.join(local, 'text_encoder') if local else None, dtype,
-                                          hidden_size=unet_config.cross_attention_dim).to('cuda')
+        vae = AutoencoderKL()
+        te_dir = os.path.join(local, 'text_encoder') if local else None
+        if local and os.path.isdir(os.path.join(local, 'vae')):
+            load_local_vae_weights(vae, local)
+        elif pretrained:
+            raise FileNotFoundError(f'pretrained=True but {local}/vae holds no weights: the frozen VAE would be random '
+                                    '(reference models.py:80-85 always loads it)')
+        else:
+            warnings.warn('AutoencoderKL is RANDOM-INIT (no local checkpoint directory): fine for throughput runs and '
+                          'tests, meaningless for real training with precomputed_latents=False or for generate()')
+        if pretrained and not (te_dir and os.path.isdir(te_dir)):
+            raise FileNotFoundError(f'pretrained=True but {te_dir} is missing: the frozen text encoder would be random')
+        vae = vae.to('cuda', dtype)
+        text_encoder = build_text_encoder(te_dir, dtype, hidden_size=unet_config.cross_attention_dim).to('cuda')
     noise_scheduler = DDPMScheduler(prediction_type=unet_config.prediction_type)
     inference_noise_scheduler = DDIMScheduler(prediction_type=unet_config.prediction_type)
 

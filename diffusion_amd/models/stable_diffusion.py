@@ -150,7 +150,12 @@ class StableDiffusion(ComposerModel):
 
     def forward(self, batch, timesteps: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
         """Returns ``(unet_out, target, timesteps)`` like the reference (:183).  ``timesteps`` / ``noise`` may be
-        injected for parity tests; by default they are drawn from torch's global RNG exactly as :177-179 do."""
+        injected for parity tests (as arguments, or as ``batch['_timesteps']`` / ``batch['_noise']`` so that they pass
+        through a trainer's microbatch slicing); by default they are drawn from torch's global RNG exactly as :177-179."""
+        if timesteps is None:
+            timesteps = batch.get('_timesteps')
+        if noise is None:
+            noise = batch.get('_noise')
         latents, conditioning = self._encode(batch)
         unet: UNetHIP = self.unet
         dev = unet.device_

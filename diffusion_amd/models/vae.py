@@ -43,6 +43,17 @@ class _Attn(nn.Module):
         return x + self.to_out[0](o).transpose(1, 2).reshape(b, c, h, w)
 
 
+class _Resample(nn.Module):
+    """diffusers Downsample2D / Upsample2D keep their convolution under ``.conv`` (state_dict key ``....0.conv.weight``)."""
+
+    def __init__(self, c, stride, padding):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=stride, padding=padding)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
 class _Mid(nn.Module):
 
     def __init__(self, c):
@@ -59,7 +70,7 @@ class _Down(nn.Module):
     def __init__(self, cin, cout, down):
         super().__init__()
         self.resnets = nn.ModuleList([_Res(cin, cout), _Res(cout, cout)])
-        self.downsamplers = nn.ModuleList([nn.Conv2d(cout, cout, 3, stride=2, padding=0)]) if down else None
+        self.downsamplers = nn.ModuleList([_Resample(cout, 2, 0)]) if down else None
 
     def forward(self, x):
         for r in self.resnets:
@@ -74,7 +85,7 @@ class _Up(nn.Module):
     def __init__(self, cin, cout, up):
         super().__init__()
         self.resnets = nn.ModuleList([_Res(cin if i == 0 else cout, cout) for i in range(3)])
-        self.upsamplers = nn.ModuleList([nn.Conv2d(cout, cout, 3, padding=1)]) if up else None
+        self.upsamplers = nn.ModuleList([_Resample(cout, 1, 1)]) if up else None
 
     def forward(self, x):
         for r in self.resnets:

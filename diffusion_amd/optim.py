@@ -60,9 +60,14 @@ class FusedAdamW(torch.optim.Optimizer):
         self.unet.grad.zero_()
 
     def state_dict(self):
+        """CPU copies (a checkpoint must not alias live device buffers that the next step overwrites)."""
         u = self.unet
-        return {'step': u.opt_step, 'exp_avg': u.exp_avg, 'exp_avg_sq': u.exp_avg_sq,
-                'param_groups': [{k: v for k, v in self.param_groups[0].items() if k != 'params'}]}
+        sd = {'step': u.opt_step, 'exp_avg': u.exp_avg.detach().cpu().clone(), 'exp_avg_sq': u.exp_avg_sq.detach().cpu().clone(),
+              'param_groups': [{k: v for k, v in self.param_groups[0].items() if k != 'params'}]}
+        if self.ema is not None:
+            sd['ema'] = self.ema.detach().cpu().clone()
+            sd['ema_smoothing'] = self.ema_smoothing
+        return sd
 
     def load_state_dict(self, sd):
         u = self.unet
@@ -71,3 +76,6 @@ class FusedAdamW(torch.optim.Optimizer):
         u.exp_avg_sq.copy_(sd['exp_avg_sq'])
         for k, v in sd['param_groups'][0].items():
             self.param_groups[0][k] = v
+        if 'ema' in sd:
+            self.ema = sd['ema'].to(device=u.master.device, dtype=u.master.dtype).clone()
+            self.ema_smoothing = float(sd['ema_smoothing'])

@@ -10,6 +10,14 @@ fixed launch/latency cost, so FEW LARGE buckets win; the flat buffer is laid out
 completes it back-to-front, and each bucket [lo, hi) is handed to RCCL on a side stream as soon as every gradient
 at offsets >= lo is final.  The sum is left un-normalised: 1/world (and 1/microbatches) is folded into the fused
 AdamW kernel's ``grad_scale``.
+
+The exchange itself is selectable (constructor arguments or the environment):
+  collective  'allreduce' (default) one ``all_reduce`` per bucket (RCCL picks ring / tree / direct for the mesh);
+              'rs_ag'     ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` per bucket: on the xGMI full mesh
+                          every rank sends shard j straight to peer j, all 7 links busy at once
+  payload     'fp32' (default) the gradient as it lies; 'bf16' a bf16 staging copy (half the bytes on the links; the
+              SUM is then rounded to 8 significant bits per element - opt-in).
+  DA_DP_COLLECTIVE / DA_DP_PAYLOAD override the defaults.
 """
 from __future__ import annotations
 
@@ -21,7 +29,8 @@ import torch.distributed as dist
 
 class BucketedAllReducer:
 
-    def __init__(self, flat_grad: torch.Tensor, bucket_elems: int = 64 * 1024 * 1024, group=None, align: int = 64):
+    def __init__(self, flat_grad: torch.Tensor, bucket_elems: int = 64 * 1024 * 1024, group=None, align: int = 64,
+                 collective: Optional[str] = None, payload: Optional[str] = None):
         if flat_grad.dim() != 1 or not flat_grad.is_contiguous():
             raise ValueError('flat_grad must be a contiguous 1-D tensor')
         self.flat = flat_grad
@@ -35,6 +44,36 @@ class BucketedAllReducer:
         self.stream: Optional[torch.cuda.Stream] = torch.cuda.Stream() if flat_grad.is_cuda else None
         # optional per-bucket continuation, run stream-ordered behind the bucket's all-reduce (e.g. its AdamW slice)
         self.on_bucket = None
+        import os
+        self.collective = collective or os.environ.get('DA_DP_COLLECTIVE', 'allreduce')
+        self.payload = payload or os.environ.get('DA_DP_PAYLOAD', 'fp32')
+        if self.collective not in ('allreduce', 'rs_ag') or self.payload not in ('fp32', 'bf16'):
+            raise ValueError(f'collective must be allreduce|rs_ag and payload fp32|bf16, got {self.collective}, {self.payload}')
+        self._stage = {}
+
+    def _exchange(self, view: torch.Tensor):
+        """Sum ``view`` over the ranks, in place, stream-ordered on the current stream (RCCL: ``wait()`` only makes
+        the current stream wait; gloo: host-blocking)."""
+        world = dist.get_world_size(self.group)
+        n = view.numel()
+        if self.collective == 'allreduce' and self.payload == 'fp32':
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+            return
+        npad = -(-n // world) * world
+        dt = torch.bfloat16 if self.payload == 'bf16' else view.dtype
+        key = (npad, dt)
+        stage = self._stage.get(key)
+        if stage is None:   # one staging buffer per distinct bucket size (the bucket sequence repeats every step)
+            stage = self._stage[key] = torch.zeros(npad, device=view.device, dtype=dt)
+        stage[:n].copy_(view)
+        if self.collective == 'allreduce':
+            dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+        else:
+            rank = dist.get_rank(self.group)
+            shard = stage.view(world, npad // world)[rank].clone()
+            dist.reduce_scatter_tensor(shard, stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+            dist.all_gather_into_tensor(stage, shard, group=self.group, async_op=True).wait()
+        view.copy_(stage[:n])
 
     @property
     def world_size(self) -> int:
@@ -58,20 +97,12 @@ class BucketedAllReducer:
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
                 if self.enabled:
-                    h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    if self.on_bucket is not None:
-                        h.wait()  # orders the side stream behind the collective; the continuation follows on it
-                    else:
-                        self.handles.append(h)
+                    self._exchange(view)     # ordered on the side stream; the continuation follows on it
                 if self.on_bucket is not None:
                     self.on_bucket(lo, hi)
         else:
             if self.enabled:
-                h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                if self.on_bucket is not None:
-                    h.wait()
-                else:
-                    self.handles.append(h)
+                self._exchange(view)
             if self.on_bucket is not None:
                 self.on_bucket(lo, hi)
 

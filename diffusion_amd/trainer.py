@@ -89,15 +89,15 @@ class Trainer:
                  device_train_microbatch_size: Optional[int] = None, schedulers=None, callbacks=None, loggers=None,
                  algorithms=None, eval_dataloader=None, eval_interval=None, device='gpu', run_name=None, seed=None,
                  scale_schedule_ratio: float = 1.0, save_folder=None, save_interval=None, save_overwrite=True,
-                 autoresume=False, fsdp_config=None, precision=None, log_every: int = 10, **unused):
+                 autoresume=False, load_path=None, fsdp_config=None, precision=None, log_every: int = 10, **unused):
         self.model = model
         self.dataloader = train_dataloader
         self.optimizer: FusedAdamW = optimizers
         self.max_batches, unit = _parse_time(max_duration)
         if unit != 'ba':
             raise ValueError('max_duration must be given in batches (e.g. 550000ba)')
-        # 'auto' (Composer's spelling) or None = the whole per-device batch in one pass: 288 GB of HBM holds the
-        # activations of 256 images and large M fills the 256-CU tile grids (1150 vs 330 images/s at microbatch 16)
+        # 'auto' (Composer's spelling) or None: as many images per pass as the card's memory holds - large M fills the
+        # 256-CU tile grids (1390 vs 368 images/s at microbatch 256 vs 16) - resolved per batch by auto_microbatch()
         self.microbatch = None if device_train_microbatch_size in (None, 'auto') else int(device_train_microbatch_size)
         self.scheduler = schedulers
         self.callbacks: List[Callback] = [c for c in (callbacks or []) if isinstance(c, Callback)]
@@ -113,6 +113,41 @@ class Trainer:
         self.global_batch_size = None
         self.logs: List[dict] = []
         self.log_every = log_every
+        self._auto_mb = {}
+        # resume: explicit load_path, or (autoresume) the newest checkpoint of this rank-0 run in save_folder
+        self.all_algorithms = list(algorithms or [])
+        if load_path:
+            self.load_checkpoint(load_path)
+        elif autoresume:
+            if not save_folder:
+                raise ValueError('autoresume=True needs save_folder')
+            latest = self.latest_checkpoint(save_folder)
+            if latest:
+                self.load_checkpoint(latest)
+
+    # saved-activation bytes per image of one forward at latent side S (bf16 activations kept for backward, measured:
+    # ~60 GB for 256 images at 32^2 -> 0.235 GB/image; the count scales with the pixel count)
+    ACT_GB_PER_IMAGE_AT_32 = 0.235
+
+    def auto_microbatch(self, n: int, latent_side: int) -> int:
+        """Composer's ``device_train_microbatch_size: auto`` shrinks the microbatch until it fits; here it is computed:
+        the largest divisor-free chunk of the per-device batch whose saved activations fit the free HBM (with 25 %
+        head-room for workspaces and the allocator), never more than the batch itself."""
+        key = (n, latent_side)
+        if key not in self._auto_mb:
+            free, _ = torch.cuda.mem_get_info()
+            free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()   # cached blocks are reusable
+            per_image = self.ACT_GB_PER_IMAGE_AT_32 * (latent_side / 32.0)**2 * 2**30
+            cap = max(1, int(0.75 * free / per_image))
+            mb = n
+            if cap < n:
+                parts = -(-n // cap)
+                mb = -(-n // parts)      # equal-sized microbatches
+            self._auto_mb[key] = mb
+            if self.rank == 0 and mb != n:
+                print(f'device_train_microbatch_size=auto -> {mb} (batch {n}, latents {latent_side}x{latent_side}, '
+                      f'{free / 2**30:.0f} GiB free)', flush=True)
+        return self._auto_mb[key]
 
     def log(self, d):
         d = dict(d, batch=self.batch_idx)
@@ -125,7 +160,11 @@ class Trainer:
         model, unet = self.model, self.model.unet
         n = next(v.shape[0] for v in batch.values() if torch.is_tensor(v))
         self.global_batch_size = n * self.world
-        mb = self.microbatch or n
+        mb = self.microbatch
+        if mb is None:
+            lat = batch.get(model.image_latents_key) if model.precomputed_latents else batch.get(model.image_key)
+            side = 32 if lat is None else (lat.shape[-1] if model.precomputed_latents else lat.shape[-1] // 8)
+            mb = self.auto_microbatch(n, side)
         unet.zero_grad()
         total = torch.zeros((), device=unet.device_)
         starts = list(range(0, n, mb))
@@ -187,18 +226,40 @@ class Trainer:
     def eval(self, subset_num_batches=None):  # evaluation (FID / sampling) is outside the hot path
         return {}
 
-    # checkpoints keep the reference layout state['state']['model'] with diffusers key names under 'unet.'
+    # checkpoints keep the reference layout state['state']['model'] with diffusers key names under 'unet.' (what
+    # diffusion/inference/inference_model.py:35-39 reads); optimizer moments, the EMA shadow and every algorithm's state
+    # (Composer checkpoints algorithm state; reference EMA: algorithms/ema.py:280-336) ride along as CPU copies
     def save_checkpoint(self, path):
         if self.rank != 0:
             return
         os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
         unet = self.model.unet
+        algs = {type(a).__name__: a.state_dict() for a in self.all_algorithms if hasattr(a, 'state_dict')}
+        tmp = path + '.tmp'
         torch.save({'state': {'model': {f'unet.{k}': v.detach().cpu().contiguous() for k, v in unet.state_dict().items()},
-                              'optimizers': self.optimizer.state_dict(), 'batch': self.batch_idx}}, path)
+                              'optimizers': self.optimizer.state_dict(), 'algorithms': algs, 'batch': self.batch_idx}}, tmp)
+        os.replace(tmp, path)   # a killed run never leaves a half-written newest checkpoint for autoresume
+
+    @staticmethod
+    def latest_checkpoint(folder: str):
+        import glob
+        import re
+        best = None
+        for f in glob.glob(os.path.join(folder, 'ba*-rank0.pt')):
+            m = re.search(r'ba(\d+)-rank0\.pt$', f)
+            if m and (best is None or int(m.group(1)) > best[0]):
+                best = (int(m.group(1)), f)
+        return best[1] if best else None
 
     def load_checkpoint(self, path):
         ck = torch.load(path, map_location='cpu')
         sd = {k[len('unet.'):]: v for k, v in ck['state']['model'].items() if k.startswith('unet.')}
         self.model.unet.load_state_dict(sd)
         self.optimizer.load_state_dict(ck['state']['optimizers'])
+        algs = ck['state'].get('algorithms', {})
+        for a in self.all_algorithms:
+            if type(a).__name__ in algs and hasattr(a, 'load_state_dict'):
+                a.load_state_dict(algs[type(a).__name__])
         self.batch_idx = ck['state']['batch']
+        if hasattr(self.dataloader, 'set_epoch') and hasattr(self.dataloader, '__len__') and len(self.dataloader):
+            self.dataloader.set_epoch(self.batch_idx // len(self.dataloader))

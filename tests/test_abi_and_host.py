@@ -255,3 +255,80 @@ def test_mds_samples_without_latents_are_skipped(tmp_path):
         ref = torch.from_numpy(np.frombuffer(samples[j]['latents_512'], np.float16).copy()).reshape(4, 64, 64)
         assert torch.equal(got[i], ref), (i, j)
     assert dl.dataset.datasets[0].skipped == 5
+
+
+def test_mds_reader_on_byte_level_fixture(tmp_path):
+    """A shard assembled BYTE BY BYTE with ``struct`` from the published MDS layout - independently of
+    diffusion_amd.datasets.mds.write_mds - with the column set of scripts/precompute_latents.py:252-272: columns sorted
+    by name, per-sample uint32 size prefix for every variable-size column, the JSON config blob between the offset table
+    and the samples, absolute offsets, and b'' for latents_512 of an image below 512 px (:303-306)."""
+    import json
+    import struct
+    import numpy as np
+    from diffusion_amd.datasets.mds import MDSDirectory
+    from diffusion_amd.datasets.laion.laion import build_streaming_laion_dataloader
+    columns = {'punsafe': 'float64', 'pwatermark': 'float64', 'similarity': 'float64', 'caption': 'str', 'url': 'str',
+               'key': 'str', 'status': 'str', 'error_message': 'str', 'width': 'int32', 'height': 'int32',
+               'original_width': 'int32', 'original_height': 'int32', 'exif': 'str', 'jpg': 'bytes', 'hash': 'int64',
+               'aesthetic_score': 'float64', 'caption_latents': 'bytes', 'latents_256': 'bytes', 'latents_512': 'bytes'}
+    names = sorted(columns)
+    encs = [columns[n] for n in names]
+    fixed = {'float64': 8, 'int32': 4, 'int64': 8}
+    sizes = [fixed.get(e) for e in encs]
+    pack = {'float64': lambda v: struct.pack('<d', v), 'int32': lambda v: struct.pack('<i', v),
+            'int64': lambda v: struct.pack('<q', v), 'str': lambda v: v.encode('utf-8'), 'bytes': lambda v: v}
+    rng = np.random.default_rng(7)
+    rows = []
+    for i in range(5):
+        big = i % 2 == 0
+        rows.append({'punsafe': 0.01 * i, 'pwatermark': 0.5, 'similarity': 0.3, 'caption': f'caf\u00e9 {i}', 'url': f'http://x/{i}',
+                     'key': f'{i:09d}', 'status': 'success', 'error_message': '', 'width': 600 if big else 300,
+                     'height': 512 if big else 280, 'original_width': 1200, 'original_height': 900, 'exif': '{}',
+                     'jpg': bytes(rng.integers(0, 255, 40 + i, dtype=np.uint8)), 'hash': -123456789012 - i,
+                     'aesthetic_score': 5.5, 'caption_latents': rng.standard_normal((77, 1024)).astype('<f2').tobytes(),
+                     'latents_256': rng.standard_normal((4, 32, 32)).astype('<f2').tobytes(),
+                     'latents_512': rng.standard_normal((4, 64, 64)).astype('<f2').tobytes() if big else b''})
+    blobs = []
+    for r in rows:
+        payload = [pack[e](r[n]) for n, e in zip(names, encs)]
+        head = b''.join(struct.pack('<I', len(p)) for p, s in zip(payload, sizes) if s is None)
+        blobs.append(head + b''.join(payload))
+    config = json.dumps({'column_encodings': encs, 'column_names': names, 'column_sizes': sizes, 'compression': None,
+                         'format': 'mds', 'hashes': [], 'size_limit': 1 << 28, 'version': 2}, sort_keys=True).encode()
+    n = len(blobs)
+    first = 4 + 4 * (n + 1) + len(config)
+    offsets, pos = [], first
+    for b in blobs:
+        offsets.append(pos)
+        pos += len(b)
+    offsets.append(pos)
+    shard = struct.pack('<I', n) + struct.pack(f'<{n + 1}I', *offsets) + config + b''.join(blobs)
+    d = tmp_path / 'mds'
+    d.mkdir()
+    (d / 'shard.00000.mds').write_bytes(shard)
+    index = {'version': 2, 'shards': [{'column_encodings': encs, 'column_names': names, 'column_sizes': sizes,
+                                       'compression': None, 'format': 'mds', 'hashes': [],
+                                       'raw_data': {'basename': 'shard.00000.mds', 'bytes': len(shard), 'hashes': {}},
+                                       'samples': n, 'size_limit': 1 << 28, 'version': 2, 'zip_data': None}]}
+    (d / 'index.json').write_text(json.dumps(index))
+    md = MDSDirectory(str(d))
+    assert len(md) == 5
+    for i, r in enumerate(rows):
+        got = md.get(i)
+        assert set(got) == set(columns)
+        for k, v in r.items():
+            if isinstance(v, float):
+                assert float(got[k]) == v, k
+            elif isinstance(v, int):
+                assert int(got[k]) == v, k
+            else:
+                assert got[k] == v, k
+    dl = build_streaming_laion_dataloader(remote=None, local=str(d), batch_size=5, resize_size=256, shuffle=False, num_workers=0)
+    b = next(iter(dl))
+    assert torch.equal(b['image_latents'][3], torch.from_numpy(np.frombuffer(rows[3]['latents_256'], '<f2').copy()).reshape(4, 32, 32))
+    assert torch.equal(b['caption_latents'][4], torch.from_numpy(np.frombuffer(rows[4]['caption_latents'], '<f2').copy()).reshape(77, 1024))
+    # 512 px: samples 1 and 3 hold b'' and are replaced by the next sample that has latents
+    dl5 = build_streaming_laion_dataloader(remote=None, local=str(d), batch_size=5, resize_size=512, shuffle=False, num_workers=0)
+    b5 = next(iter(dl5))
+    for i, j in enumerate([0, 2, 2, 4, 4]):
+        assert torch.equal(b5['image_latents'][i], torch.from_numpy(np.frombuffer(rows[j]['latents_512'], '<f2').copy()).reshape(4, 64, 64))

@@ -13,14 +13,14 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, q):
+def _worker(rank, world, port, n, q, collective='allreduce', payload='fp32'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from diffusion_amd.parallel import BucketedAllReducer
     g = torch.Generator().manual_seed(100 + rank)
     flat = torch.randn(n, generator=g)
     mine = flat.clone()
-    red = BucketedAllReducer(flat, bucket_elems=1000, align=64)
+    red = BucketedAllReducer(flat, bucket_elems=1000, align=64, collective=collective, payload=payload)
     assert red.enabled and red.world_size == world
     red.begin()
     # gradients become final back-to-front, in uneven block sizes (like the U-Net's tape walk)
@@ -35,7 +35,8 @@ def _worker(rank, world, port, n, q):
         covered[a:b] += 1
     others = [torch.empty(n) for _ in range(world)]
     dist.all_gather(others, mine)
-    ok = bool((covered == 1).all()) and torch.allclose(flat, sum(others), atol=1e-6)
+    tol = 1e-6 if payload == 'fp32' else 0.05   # bf16 payload: each addend and the sum rounded to 8 bits
+    ok = bool((covered == 1).all()) and torch.allclose(flat, sum(others), atol=tol)
     big = [b - a for a, b in red.launched[:-1]]
     ok = ok and all(x >= 1000 for x in big)
     q.put((rank, ok, len(red.launched)))
@@ -43,12 +44,16 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_gloo_world2():
-    world, n = 2, 6000
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('collective,payload', [('allreduce', 'fp32'), ('rs_ag', 'fp32'), ('allreduce', 'bf16'), ('rs_ag', 'bf16')])
+def test_bucketed_allreduce_gloo_world2(collective, payload):
+    world, n = 2, 6001   # odd length: reduce-scatter shards need padding
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, collective, payload)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]

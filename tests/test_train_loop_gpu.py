@@ -91,3 +91,63 @@ def test_sliced_optimizer_matches_single_launch(dev):
     loss = tr.train_batch(batch)
     torch.cuda.synchronize()
     assert torch.isfinite(loss) and len(tr.reducer.launched) > 2 and u.opt_step == step0 + 1
+
+
+def test_checkpoint_keeps_ema_and_resume_continues_it(dev, tmp_path):
+    """Composer checkpoints algorithm state, so the reference's EMA survives a resume (algorithms/ema.py:280-336).  Train
+    6 batches with EMA from batch 2, checkpointing at 4; a new Trainer with load_path (and one with autoresume) restores
+    weights, moments, the EMA shadow and ema_started, and two more batches land on the uninterrupted run's EMA."""
+    from diffusion_amd import hydra_lite as h
+    from diffusion_amd.train import train
+    base = ['batch_size=4', 'model.model_name=tiny', 'trainer.device_train_microbatch_size=4',
+            'dataset.train_dataset.num_workers=0', 'dataset.train_dataset.text_dim=128', 'dataset.train_dataset.resize_size=64',
+            'dataset.train_dataset.num_samples=4', 'dataset.train_dataset.shuffle=false', 'algorithms.ema.ema_start=2ba',
+            'algorithms.ema.smoothing=0.5', 'optimizer.lr=1.0e-3', 'scheduler.t_warmup=0ba', f'trainer.save_folder={tmp_path}',
+            'trainer.save_interval=4ba']
+    path = os.path.join(ROOT, 'yamls', 'hydra-yamls', 'SD-2-base-512.yaml')
+    torch.manual_seed(0)
+    full = train(h.load_config(path, base + ['trainer.max_duration=4ba']))
+    ck = os.path.join(tmp_path, 'ba4-rank0.pt')
+    st = torch.load(ck, map_location='cpu')['state']
+    assert st['algorithms']['EMA']['ema_started'] is True and 'ema' in st['optimizers']
+    assert st['optimizers']['exp_avg'].device.type == 'cpu'
+    assert torch.equal(st['optimizers']['ema'], full.optimizer.ema.cpu())
+    ema4, w4 = full.optimizer.ema.clone(), full.model.unet.master.clone()
+    for extra in ([f'trainer.load_path={ck}'], ['trainer.autoresume=true']):
+        tr = train(h.load_config(path, base + ['trainer.max_duration=4ba'] + extra))   # already at batch 4: nothing to do
+        assert tr.batch_idx == 4 and tr.algorithms[0].ema_started
+        assert torch.equal(tr.optimizer.ema, ema4) and torch.equal(tr.model.unet.master, w4)
+        assert tr.model.unet.opt_step == 4
+    # continuing must NOT re-seed the average from the live weights
+    tr = train(h.load_config(path, base + ['trainer.max_duration=5ba', f'trainer.load_path={ck}']))
+    assert tr.batch_idx == 5
+    expect_if_reseeded = tr.model.unet.master
+    assert not torch.equal(tr.optimizer.ema, expect_if_reseeded)
+    # ema_5 = 0.5 * ema_4 + 0.5 * w_5 exactly (fused in the AdamW kernel)
+    assert torch.allclose(tr.optimizer.ema, 0.5 * ema4 + 0.5 * tr.model.unet.master, atol=1e-6)
+
+
+def test_auto_microbatch_fits_memory(dev, monkeypatch):
+    """device_train_microbatch_size: auto (the YAML default) must bound the microbatch by free HBM instead of taking the
+    whole per-device batch (Composer's 'auto' shrinks until it fits)."""
+    from diffusion_amd.models.models import stable_diffusion_2
+    from diffusion_amd.optim import FusedAdamW
+    from diffusion_amd.trainer import Trainer
+    model = stable_diffusion_2(model_name='tiny', pretrained=False, precomputed_latents=True, fsdp=False, seed=3)
+    opt = FusedAdamW(lr=1e-3, unet=model.unet)
+    tr = Trainer(model, train_dataloader=None, optimizers=opt, max_duration='1ba', device_train_microbatch_size='auto')
+    assert tr.auto_microbatch(256, 32) == 256 and tr.auto_microbatch(64, 64) == 64     # 288 GB: the bench settings fit
+    tr._auto_mb.clear()
+    gib = 2**30
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda *a: (80 * gib, 288 * gib))
+    monkeypatch.setattr(torch.cuda, 'memory_reserved', lambda *a: 0)
+    monkeypatch.setattr(torch.cuda, 'memory_allocated', lambda *a: 0)
+    assert tr.auto_microbatch(256, 32) == 128          # 60 GiB budget / 0.235 GiB per image -> 255 max -> 2 equal parts
+    assert tr.auto_microbatch(256, 64) == 52           # 0.94 GiB per image -> 63 max -> 5 parts of <= 52
+    assert tr.auto_microbatch(2048, 32) <= 255
+    g = torch.Generator().manual_seed(5)
+    batch = {'image_latents': torch.randn(6, 4, 16, 16, generator=g).half().to(dev),
+             'caption_latents': torch.randn(6, 77, 128, generator=g).half().to(dev)}
+    tr._auto_mb[(6, 16)] = 4                           # force a ragged split 4 + 2 through the same code path
+    loss = tr.train_batch(batch)
+    assert torch.isfinite(loss)
