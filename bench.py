@@ -39,6 +39,20 @@ PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MIC
 README_8xA100 = {32: 1100.0, 64: 290.0}  # /root/reference README.md:56 (8xA100, global batch 2048)
 
 
+def _usable_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a 1-GPU
+    job a share of the host, and 128 threads on a 16-core share only thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(seconds_budget=30.0):
     """Oracle (CPU port of the same training step, fp32) on the host cores.
 
@@ -49,6 +63,7 @@ def cpu_baseline(seconds_budget=30.0):
     cfg 1 as written instead (batch 4, 1 warm-up + median of 3)."""
     from oracle import unet_oracle as O
     cfg = O.UNetConfig.sd2_base()
+    torch.set_num_threads(_usable_cores())
     torch.manual_seed(17)
     sd = {}
     for k, shape in O.param_manifest(cfg):  # fast init: statistics as init_state_dict, cheaper RNG

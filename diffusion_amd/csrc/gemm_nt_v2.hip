@@ -38,6 +38,8 @@ struct GemmNT2Params {
   bf16* G;                       // GEGLU variant: gated output [M][inner] (C then holds the pre-activation [M][2*inner])
   long ldg;
   int inner;                     // GEGLU variant: hidden width; W rows [0, inner) = value, [inner, 2*inner) = gate
+  int korder;                    // 3x3 K-loop order: 0 = tap-major (k = tap*Cin + c, as W is laid out), 1 = channel-chunk-major
+                                 // with the 9 taps innermost (see the K-loop comment)
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
@@ -173,9 +175,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
   const int kstep_begin = split * p.ksteps_per_split;
   const int nk_total = p.K / V2_BK;
   const int nk = min(p.ksteps_per_split, nk_total - kstep_begin);
-  int k0 = kstep_begin * V2_BK;
-  int tap = k0 / p.Cin;
-  int c0 = k0 - tap * p.Cin;
+  // K-loop order.  W is [n][tap][c], and walking k linearly visits tap 0 of all Cin channels, then tap 1, ...: the 9
+  // shifted reads of one activation row are Cin/64 steps apart, and with every CU of an XCD streaming its own row block
+  // (32 x Cin/64 x 32 KiB between two taps) they fall out of the 4 MiB L2: 1.68 GB of fabric reads per launch on the
+  // 320-channel 32x32 layers where 0.34 GB is algorithmic (rocprofv3 FETCH_SIZE, L2 hit 58 %).  korder 1 walks one
+  // 64-channel chunk through its 9 taps before the next chunk: the re-reads are consecutive steps over a ~42 KiB footprint.
+  // Same products, summed in a different order.
+  const bool tap_inner = p.korder != 0 && ntaps > 1;
+  int tap, c0;
+  if (tap_inner) {
+    const int ch = kstep_begin / ntaps;
+    tap = kstep_begin - ch * ntaps;
+    c0 = ch * V2_BK;
+  } else {
+    const int kb = kstep_begin * V2_BK;
+    tap = kb / p.Cin;
+    c0 = kb - tap * p.Cin;
+  }
   // live == false (the step after the last): A reads the zero page, B re-reads K-step 0 - no branch in the K loop
   auto issue = [&](int stage, bool live) {
     char* Ab = smem + stage * STAGE;
@@ -202,17 +218,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
         glds16(src, Ab + (wave * AJ + j) * 1024);
       }
     }
-    const bf16* wb = p.W + (live ? k0 : 0);
+    const bf16* wb = p.W + (live ? tap * p.Cin + c0 : 0);
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       const int g = wave + NW * j;
       if (BGROUPS % NW == 0 || g < BGROUPS) glds16(wb + woff[j], Bb + g * 1024);
     }
-    k0 += V2_BK;
-    c0 += V2_BK;
-    const bool wrap = c0 >= p.Cin;
-    c0 = wrap ? 0 : c0;
-    tap += wrap ? 1 : 0;
+    // advance (selects, no branch): tap-inner walks the taps of one channel chunk; tap-major walks the chunks of one tap
+    const int tap_n = tap + 1, c_n = c0 + V2_BK;
+    const bool wrap_t = tap_n >= ntaps, wrap_c = c_n >= p.Cin;
+    if (tap_inner) {
+      tap = wrap_t ? 0 : tap_n;
+      c0 = wrap_t ? c_n : c0;
+    } else {
+      c0 = wrap_c ? 0 : c_n;
+      tap = wrap_c ? tap_n : tap;
+    }
   };
 
   f32x4 acc[MT][NT];
@@ -564,6 +585,8 @@ int launch_v2(const GemmNT2Params& p, int splits, float* ws, hipStream_t stream)
 
 }  // namespace
 
+int g_nt_korder = 1;  // da_set_option("gemm_nt_korder", 0 | 1)
+
 // Called by da_gemm_nt (gemm_nt.hip) after argument validation.  variant: 4 -> BN 128, 5 -> BN 160, 10 -> BN 320.
 int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
                            const void* rowbias, long ldrb, const void* R, long ldr, int M, int N, int K, int Cin,
@@ -579,6 +602,7 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
   p.G = nullptr; p.ldg = 0; p.inner = 0;
+  p.korder = g_nt_korder;
   if (variant == 10) return launch_v2<8, 5, 2, 4, 64>(p, splits, ws, stream);
   if (variant == 11) return launch_v2<4, 10, 2, 2, 32>(p, 1, ws, stream);  // 128 x 320 x 32, 4 waves, 2 workgroups / CU
   if (variant == 12) return launch_v2<4, 5, 4, 4, 64>(p, splits, ws, stream);  // 256 x 320 x 64, 16 waves (4 / SIMD)
@@ -600,7 +624,7 @@ extern "C" int da_gemm_nt_geglu(const void* A, long lda, const void* W, void* F,
   p.ksize = 1; p.mode = 0; p.out_fp32 = 0; p.alpha = 1.0f;
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
-  p.G = (bf16*)G; p.ldg = ldg; p.inner = inner;
+  p.G = (bf16*)G; p.ldg = ldg; p.inner = inner; p.korder = 0;
   return launch_v2_geglu<1>(p, stream);
 }
 
@@ -619,6 +643,6 @@ extern "C" int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, c
   p.ksize = 1; p.mode = 0; p.out_fp32 = 0; p.alpha = 1.0f;
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
-  p.G = (bf16*)const_cast<void*>(F); p.ldg = ldf; p.inner = inner;
+  p.G = (bf16*)const_cast<void*>(F); p.ldg = ldf; p.inner = inner; p.korder = 0;
   return launch_v2_geglu<2>(p, stream);
 }

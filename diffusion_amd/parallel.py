@@ -37,14 +37,16 @@ class BucketedAllReducer:
         self.bucket = int(bucket_elems)
         self.align = align
         self.group = group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        import os
+        # DA_DP_FORCE=1: run the exchange even in a 1-rank group (lets a 1-GPU box execute the RCCL calls themselves)
+        self.enabled = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or os.environ.get('DA_DP_FORCE') == '1')
         self.hi = flat_grad.numel()
         self.handles: List = []
         self.launched: List = []  # (lo, hi) ranges, for tests
         self.stream: Optional[torch.cuda.Stream] = torch.cuda.Stream() if flat_grad.is_cuda else None
         # optional per-bucket continuation, run stream-ordered behind the bucket's all-reduce (e.g. its AdamW slice)
         self.on_bucket = None
-        import os
         self.collective = collective or os.environ.get('DA_DP_COLLECTIVE', 'allreduce')
         self.payload = payload or os.environ.get('DA_DP_PAYLOAD', 'fp32')
         if self.collective not in ('allreduce', 'rs_ag') or self.payload not in ('fp32', 'bf16'):
@@ -134,7 +136,7 @@ def init_distributed_from_env(device_index: Optional[int] = None):
         # one rank per GPU; (DA_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path on a 1-GPU box)
         n = torch.cuda.device_count()
         torch.cuda.set_device((local if device_index is None else device_index) % max(n, 1))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get('DA_DP_FORCE') == '1') and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         backend = os.environ.get('DA_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')

@@ -89,7 +89,8 @@ class Trainer:
                  device_train_microbatch_size: Optional[int] = None, schedulers=None, callbacks=None, loggers=None,
                  algorithms=None, eval_dataloader=None, eval_interval=None, device='gpu', run_name=None, seed=None,
                  scale_schedule_ratio: float = 1.0, save_folder=None, save_interval=None, save_overwrite=True,
-                 autoresume=False, load_path=None, fsdp_config=None, precision=None, log_every: int = 10, **unused):
+                 autoresume=False, load_path=None, fsdp_config=None, precision=None, log_every: int = 10,
+                 use_graphs='auto', **unused):
         self.model = model
         self.dataloader = train_dataloader
         self.optimizer: FusedAdamW = optimizers
@@ -114,6 +115,11 @@ class Trainer:
         self.logs: List[dict] = []
         self.log_every = log_every
         self._auto_mb = {}
+        # hipGraph replay of whole microbatches (graph_step.py): 'auto' = when a step has several microbatches or the
+        # microbatch is small enough to be launch-bound; True / False force it.  DA_GRAPH=0/1 overrides.
+        env = os.environ.get('DA_GRAPH')
+        self.use_graphs = use_graphs if env is None else (env == '1')
+        self._graph_cache = None
         # resume: explicit load_path, or (autoresume) the newest checkpoint of this rank-0 run in save_folder
         self.all_algorithms = list(algorithms or [])
         if load_path:
@@ -176,9 +182,11 @@ class Trainer:
         for i, s in enumerate(starts):
             sub = {k: (v[s:s + mb] if torch.is_tensor(v) else v) for k, v in batch.items()}
             w = min(mb, n - s) / n
-            outputs = model(sub)
-            loss = model.loss(outputs, sub, weight=w)
             last = i == len(starts) - 1
+            graphed = self._graph_this(sub, len(starts), last)
+            if not graphed:
+                outputs = model(sub)
+                loss = model.loss(outputs, sub, weight=w)
             if last:
                 # everything the optimizer step needs is known before the last backward: each gradient bucket is
                 # all-reduced and its AdamW slice issued on the side stream as soon as backward has finished it
@@ -188,11 +196,15 @@ class Trainer:
                 opt.grad_scale = 1.0 / self.world
                 for a in self.algorithms:
                     a.before_optimizer_step(self)
-                if sliced:
+                if sliced and not graphed:
                     opt.begin_step()
                     self.reducer.on_bucket = opt.step_range
-            unet._grad_ready_cb = self.reducer.ready if last else None
-            model.backward_from_loss()
+            if graphed:
+                unet._grad_ready_cb = None
+                outputs, loss = self._graph_cache.step(sub, w)
+            else:
+                unet._grad_ready_cb = self.reducer.ready if last else None
+                model.backward_from_loss()
             for m in model.get_metrics(is_train=True).values():
                 model.update_metric(sub, outputs, m)
             total = total + loss.detach() * w
@@ -201,6 +213,22 @@ class Trainer:
         self.reducer.on_bucket = None
         opt.step()
         return total
+
+    def _graph_this(self, sub, n_micro: int, last: bool) -> bool:
+        """Replay this microbatch from a captured hipGraph?  Never the last microbatch of a multi-rank step (its backward
+        overlaps the gradient exchange through host-side hooks)."""
+        if self.use_graphs is False or (last and self.reducer.enabled):
+            return False
+        if self._graph_cache is None:
+            from .graph_step import GraphStepCache
+            self._graph_cache = GraphStepCache(self.model)
+        if not self._graph_cache.usable(sub):
+            return False
+        if self.use_graphs is True:
+            return True
+        lat = sub[self.model.image_latents_key]
+        small = lat.shape[0] * lat.shape[-1] * lat.shape[-2] <= 64 * 1024   # <= 64 images at 32x32: launch-bound territory
+        return n_micro > 1 and small
 
     def fit(self):
         it = iter(self.dataloader)

@@ -10,6 +10,7 @@ import sys
 
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import torch  # noqa: E402
+import torch.distributed  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -42,9 +43,10 @@ def main():
         scale = 1.0 / world   # the exchanged gradient is the SUM over ranks; 1/world is folded into AdamW
         torch.save({'grad': (model.unet.grad.detach().cpu() * scale), 'before': before,
                     'after': model.unet.master.detach().cpu().clone(), 'loss': float(loss.item()),
-                    'buckets': len(tr.reducer.launched), 'world': world}, out)
-    if world > 1:
-        import torch.distributed as dist
+                    'buckets': len(tr.reducer.launched), 'world': world, 'reducer_enabled': tr.reducer.enabled,
+                    'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None)}, out)
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -49,3 +49,19 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(single, tmp_path, 
     cos = torch.nn.functional.cosine_similarity(u1.flatten(), u2.flatten(), dim=0).item()
     assert cos > 0.99, cos
     assert u1.abs().max() > 0
+
+
+@pytest.mark.parametrize('collective,payload', [('allreduce', 'fp32'), ('rs_ag', 'fp32'), ('rs_ag', 'bf16')])
+def test_rccl_calls_execute_in_a_one_rank_group(single, tmp_path, collective, payload):
+    """A 1-GPU box cannot hold two RCCL ranks, but it can run the RCCL code path itself: backend 'nccl' (= RCCL) with
+    device_id, bucketed collectives on the side stream, HSA_ENABLE_IPC_MODE_LEGACY=0 - in a world of one, where the sum
+    over ranks is the identity, so the step must reproduce the plain single-process step."""
+    env = {'DA_DP_FORCE': '1', 'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1',
+           'MASTER_PORT': '29618', 'DA_DP_COLLECTIVE': collective, 'DA_DP_PAYLOAD': payload}
+    one = _run(str(tmp_path / 'one.pt'), 1, env)
+    assert one['backend'] == 'nccl' and one['reducer_enabled'] and one['buckets'] >= 3
+    if payload == 'fp32':
+        assert torch.equal(one['grad'], single['grad']) and torch.equal(one['after'], single['after'])
+    else:   # bf16 staging copy rounds every gradient element to 8 significant bits
+        rel = ((one['grad'] - single['grad']).norm() / single['grad'].norm()).item()
+        assert rel < 5e-3, rel
