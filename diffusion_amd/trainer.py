@@ -90,7 +90,7 @@ class Trainer:
                  algorithms=None, eval_dataloader=None, eval_interval=None, device='gpu', run_name=None, seed=None,
                  scale_schedule_ratio: float = 1.0, save_folder=None, save_interval=None, save_overwrite=True,
                  autoresume=False, load_path=None, fsdp_config=None, precision=None, log_every: int = 10,
-                 use_graphs='auto', **unused):
+                 use_graphs=False, **unused):
         self.model = model
         self.dataloader = train_dataloader
         self.optimizer: FusedAdamW = optimizers
@@ -115,8 +115,10 @@ class Trainer:
         self.logs: List[dict] = []
         self.log_every = log_every
         self._auto_mb = {}
-        # hipGraph replay of whole microbatches (graph_step.py): 'auto' = when a step has several microbatches or the
-        # microbatch is small enough to be launch-bound; True / False force it.  DA_GRAPH=0/1 overrides.
+        # hipGraph replay of whole microbatches (graph_step.py): True / False, or 'auto' = when a step has several small
+        # microbatches.  Off by default: measured on MI355X the step is GPU-bound even at the reference YAML's microbatch
+        # of 16 (372.4 images/s eager vs 372.4 replayed: the small-M kernels, not the ~1,700 launches, set the time), so
+        # replay buys nothing there and costs a private memory pool per captured signature.  DA_GRAPH=0/1 overrides.
         env = os.environ.get('DA_GRAPH')
         self.use_graphs = use_graphs if env is None else (env == '1')
         self._graph_cache = None

@@ -1,6 +1,6 @@
 """A/B of one da_set_option key on the U-Net's 3x3-conv (implicit GEMM) shapes, interleaved rounds in ONE process
 (median and min per arm), with a closeness check between the two arms' outputs.
-usage: opt_ab.py <option> <valA> <valB> [B=256] [kinds=conv,lin]"""
+usage: opt_ab.py <option> <valA> <valB> [B=256] [kinds=conv,lin] [key=val ...]   (key=val: options fixed for both arms)"""
 import sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,17 +8,6 @@ from diffusion_amd import ops
 from diffusion_amd.ops import Geom
 
 dev = torch.device('cuda'); BF = torch.bfloat16
-opt, va, vb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-B = int(sys.argv[4]) if len(sys.argv) > 4 else 256
-kinds = (sys.argv[5] if len(sys.argv) > 5 else 'conv').split(',')
-ops.SPLITK_WS = torch.empty(32 * 1024 * 1024, device=dev, dtype=torch.float32)
-shapes = []
-if 'conv' in kinds:
-    shapes += [(32, 320, 320, 3), (16, 640, 640, 3), (8, 1280, 1280, 3), (4, 1280, 1280, 3), (32, 960, 320, 3), (32, 640, 320, 3),
-               (16, 1920, 640, 3), (16, 1280, 640, 3), (8, 2560, 1280, 3), (16, 320, 640, 3), (8, 640, 1280, 3)]
-if 'lin' in kinds:
-    for (h, c) in ((32, 320), (16, 640), (8, 1280)):
-        shapes += [(h, c, c, 1), (h, 4 * c, c, 1), (h, c, 3 * c, 1)]
 
 
 def once(fn, iters):
@@ -30,23 +19,59 @@ def once(fn, iters):
     return s.elapsed_time(e) / iters
 
 
+opt, va, vb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+kinds = (sys.argv[5] if len(sys.argv) > 5 else 'conv').split(',')
+ops.SPLITK_WS = torch.empty(32 * 1024 * 1024, device=dev, dtype=torch.float32)
+for kv in sys.argv[6:]:
+    k_, v_ = kv.split('=')
+    ops.set_option(k_, int(v_))
+shapes = []
+if 'conv' in kinds:
+    shapes += [(32, 320, 320, 3), (16, 640, 640, 3), (8, 1280, 1280, 3), (4, 1280, 1280, 3), (32, 960, 320, 3), (32, 640, 320, 3),
+               (16, 1920, 640, 3), (16, 1280, 640, 3), (8, 2560, 1280, 3), (16, 320, 640, 3), (8, 640, 1280, 3)]
+if 'lin' in kinds:
+    for (h, c) in ((32, 320), (16, 640), (8, 1280)):
+        shapes += [(h, c, c, 1), (h, 4 * c, c, 1), (h, c, 3 * c, 1)]
+
+
+if 'geglu' in kinds:
+    import statistics as st
+    for (h, c) in ((32, 320), (16, 640), (8, 1280)):
+        M, K, inner = B * h * h, c, 4 * c
+        A = torch.randn(M, K, device=dev).to(BF); W = (torch.randn(2 * inner, K, device=dev) * K**-0.5).to(BF)
+        bias = torch.randn(2 * inner, device=dev)
+        f = torch.empty(M, 2 * inner, device=dev, dtype=BF); gg = torch.empty(M, inner, device=dev, dtype=BF)
+        dy = torch.randn(M, K, device=dev).to(BF); wt = (torch.randn(inner, K, device=dev) * inner**-0.5).to(BF)
+        df = torch.empty(M, 2 * inner, device=dev, dtype=BF)
+        for name, fn, fl in (('geglu_fwd', lambda: ops.gemm_nt_geglu(A, W, f, gg, bias), 2.0 * M * 2 * inner * K),
+                             ('geglu_bwd', lambda: ops.gemm_nt_geglu_bwd(dy, wt, f, df), 2.0 * M * inner * K)):
+            ts = {va: [], vb: []}
+            for rnd in range(7):
+                for v in (va, vb):
+                    ops.set_option(opt, v)
+                    fn(); ts[v].append(once(fn, 10))
+            ma, mb = st.median(ts[va]), st.median(ts[vb])
+            print(f'{name} M={M:6d} inner={inner:5d} K={K:5d} | {opt}={va}: {ma*1e3:7.1f} us {fl/ma/1e9:7.1f} TF/s | ={vb}: {mb*1e3:7.1f} us {fl/mb/1e9:7.1f} TF/s | x{ma/mb:.3f}', flush=True)
+
 for h, cin, cout, k in shapes:
     M = B * h * h
     x = torch.randn(M, cin, device=dev).to(BF)
     w = (torch.randn(cout, k * k * cin, device=dev) * (k * k * cin)**-0.5).to(BF)
     bias = torch.randn(cout, device=dev)
     g = Geom.conv(B, h, h, k)
+    res = torch.randn(M, cout, device=dev).to(BF) if k == 1 else None   # linears: the residual epilogue of to_out / proj_out
     fl = 2.0 * M * cout * k * k * cin
     ys, ts = {}, {va: [], vb: []}
     for v in (va, vb):
         ops.set_option(opt, v)
         y = torch.empty(M, cout, device=dev, dtype=BF)
-        ops.gemm_nt(x, w, y, g, bias=bias)
+        ops.gemm_nt(x, w, y, g, bias=bias, residual=res)
         ys[v] = y.float()
     for rnd in range(7):
         for v in (va, vb):
             ops.set_option(opt, v)
-            ts[v].append(once(lambda: ops.gemm_nt(x, w, y, g, bias=bias), 10))
+            ts[v].append(once(lambda: ops.gemm_nt(x, w, y, g, bias=bias, residual=res), 10))
     rel = ((ys[va] - ys[vb]).norm() / ys[va].norm()).item()
     ma, mb = statistics.median(ts[va]), statistics.median(ts[vb])
     print(f'M={M:6d} N={cout:5d} K={k*k*cin:6d} | {opt}={va}: {ma*1e3:7.1f} us {fl/ma/1e9:7.1f} TF/s (min {min(ts[va])*1e3:.1f}) | '
