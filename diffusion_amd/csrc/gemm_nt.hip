@@ -109,6 +109,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTParams p) {
       } else if (p.mode == 1) {
         ih = 2 * oh[i] + r - pad;
         iw = 2 * ow[i] + s - pad;
+      } else if (p.mode == 4) {  // stride 2 over an image zero-padded at the bottom / right only (VAE downsampler)
+        ih = 2 * oh[i] + r;
+        iw = 2 * ow[i] + s;
       } else if (p.mode == 2) {
         int th = oh[i] + r - 1, tw = ow[i] + s - 1;
         ok = ok && !((th | tw) & 1);
@@ -314,7 +317,8 @@ extern "C" int da_gemm_nt(const void* A, long lda, const void* W, void* C, long 
   if ((N & 7) || (Cin & 7) || (K % Cin) || (lda & 7) || (ldc & 7)) return DA_ERR_SHAPE;
   if (ksize != 1 && ksize != 3) return DA_ERR_SHAPE;
   if (K != ksize * ksize * Cin) return DA_ERR_SHAPE;
-  if (mode < 0 || mode > 3) return DA_ERR_SHAPE;
+  if (mode < 0 || mode > 4) return DA_ERR_SHAPE;
+  if (mode == 4 && ksize != 3) return DA_ERR_SHAPE;
   if (Hout <= 0 || Wout <= 0 || (M % (Hout * Wout))) return DA_ERR_SHAPE;
   if (R && (ldr & 7)) return DA_ERR_SHAPE;
   if (rowbias && (ldrb & 7)) return DA_ERR_SHAPE;

@@ -117,9 +117,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
     else return n0 + c;
   };
   const int HWo = p.Hout * p.Wout;
-  const int pad = (p.ksize == 3) ? 1 : 0;
-  const int gmul = (p.mode == 1) ? 2 : 1, gshift = (p.mode >= 2) ? 1 : 0, pmask = (p.mode == 2) ? 1 : 0;
-  const int hlim = (p.mode >= 2) ? 2 * p.Hin : p.Hin, wlim = (p.mode >= 2) ? 2 * p.Win : p.Win;
+  // mode 4: stride 2 with zero padding at the bottom / right only (the VAE encoder's downsampler) = mode 1 without the
+  // one-pixel shift
+  const int pad = (p.ksize == 3 && p.mode != 4) ? 1 : 0;
+  const int gmul = (p.mode == 1 || p.mode == 4) ? 2 : 1, gshift = (p.mode == 2 || p.mode == 3) ? 1 : 0, pmask = (p.mode == 2) ? 1 : 0;
+  const int hlim = gshift ? 2 * p.Hin : p.Hin, wlim = gshift ? 2 * p.Win : p.Win;
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   // bias for this column block -> LDS (behind the stage buffers), read back in the epilogue; zeros when absent
   if (tid < BN / 4) {

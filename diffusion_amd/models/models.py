@@ -108,7 +108,7 @@ def stable_diffusion_2(
 
     if build_encoders is None:
         build_encoders = not precomputed_latents
-    vae = text_encoder = None
+    vae = text_encoder = vae_hip = None
     from .text import build_text_encoder, build_tokenizer
     tokenizer = build_tokenizer(os.path.join(local, 'tokenizer') if local else None)
     if build_encoders:
@@ -126,6 +126,11 @@ def stable_diffusion_2(
                           'tests, meaningless for real training with precomputed_latents=False or for generate()')
         if pretrained and not (te_dir and os.path.isdir(te_dir)):
             raise FileNotFoundError(f'pretrained=True but {te_dir} is missing: the frozen text encoder would be random')
+        vae_hip = None
+        if os.environ.get('DA_VAE_HIP', '1') != '0':
+            # the encoder half of the frozen VAE on the HIP kernels (models/vae_hip.py), built from the fp32 weights
+            from .vae_hip import VAEEncoderHIP
+            vae_hip = VAEEncoderHIP(vae.to('cuda'))
         vae = vae.to('cuda', dtype)
         text_encoder = build_text_encoder(te_dir, dtype, hidden_size=unet_config.cross_attention_dim).to('cuda')
     noise_scheduler = DDPMScheduler(prediction_type=unet_config.prediction_type)
@@ -147,4 +152,5 @@ def stable_diffusion_2(
         encode_latents_in_fp16=encode_latents_in_fp16,
         fsdp=fsdp,
     )
+    model.vae_hip = vae_hip if build_encoders else None
     return model

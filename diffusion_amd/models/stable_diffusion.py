@@ -137,8 +137,15 @@ class StableDiffusion(ComposerModel):
             raise RuntimeError('this model was built without VAE / text encoder; pass precomputed latents')
         inputs, conditioning = batch[self.image_key], batch[self.text_key]
         conditioning = conditioning.view(-1, conditioning.shape[-1])
+        # image encoder: the HIP-kernel walk of the same frozen weights when the factory built one (models/vae_hip.py),
+        # else the PyTorch-ROCm module
+        vae_hip = getattr(self, 'vae_hip', None)
         with torch.no_grad():
-            if self.encode_latents_in_fp16:
+            if vae_hip is not None:
+                latents = vae_hip.encode(inputs)['latent_dist'].sample().data
+                with torch.autocast('cuda', enabled=False):
+                    conditioning = self.text_encoder(conditioning)[0]
+            elif self.encode_latents_in_fp16:
                 with torch.autocast('cuda', enabled=False):
                     latents = self.vae.encode(inputs.half())['latent_dist'].sample().data
                     conditioning = self.text_encoder(conditioning)[0]

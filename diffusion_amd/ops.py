@@ -98,6 +98,10 @@ class Geom:
         return Geom(B, H, W, H // 2, W // 2, 3, 1)
 
     @staticmethod
+    def down_vae(B, H, W):  # stride-2 conv over an image zero-padded at the bottom / right only (VAE encoder downsampler)
+        return Geom(B, H, W, H // 2, W // 2, 3, 4)
+
+    @staticmethod
     def down_dgrad(B, H, W):  # dgrad of the above: "input" dY at H/2, output dX at H
         return Geom(B, H // 2, W // 2, H, W, 3, 2)
 

@@ -34,7 +34,8 @@ typedef struct ihipStream_t* da_stream_t; /* == hipStream_t */
  * Transformer2DModel, reached from stable_diffusion.py:183; with the transposed weight shadow it is also
  * their dgrad in backward.  K = ksize*ksize*Cin; W is [N][kh][kw][Cin]; M = B*Hout*Wout.
  * mode 0: stride 1 (pad 1 when ksize 3); 1: stride 2 pad 1 (Downsample2D); 2: dgrad of mode 1 (A = dY at
- * Hin x Win = half resolution); 3: 3x3 conv over the nearest-2x upsampled A (Upsample2D), Hout = 2*Hin.
+ * Hin x Win = half resolution); 3: 3x3 conv over the nearest-2x upsampled A (Upsample2D), Hout = 2*Hin; 4: stride 2 with
+ * zero padding at the bottom / right only (AutoencoderKL encoder Downsample2D: F.pad(x, (0,1,0,1)) + conv stride 2).
  * out_fp32: C is float* (else bf16).  splitk_ws (may be NULL): fp32 workspace of splitk_ws_floats elements; when the
  * tile grid alone would leave most CUs idle (small M) the K loop is split over up to 8 workgroups per tile whose
  * partial slabs (splits*M*N floats) are summed by a fused finalize pass. */
