@@ -262,12 +262,13 @@ static int g_nt_splitk = 1;  // da_set_option("gemm_nt_splitk", 0/1)  // 0 auto,
 static int pick_nt_variant(int M, int N, int K, int Cin, long ws_floats, int* splits) {
   *splits = 1;
   if (Cin % 64 != 0) return 1;
-  if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10 || g_nt_variant == 11 || g_nt_variant == 12) return g_nt_variant;
+  if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10 || g_nt_variant == 11 || g_nt_variant == 12 || g_nt_variant == 14) return g_nt_variant;
   if (g_nt_variant != 0) return 1;
   // one 512-thread workgroup per CU: pick the largest tile that still keeps most of the 256 CUs busy
   const long tm = (M + 255) / 256;
   if (N % 320 == 0 && tm * (N / 320) >= 160) return 12;
   if (N % 160 == 0 && tm * (N / 160) >= 200) return 5;
+  if (N % 256 == 0 && tm * (N / 256) >= 160) return 14;  // channel counts of the VAE encoder (256, 512): 16-wave 256 x 256 tile
   if (N % 160 != 0 && tm * ((N + 127) / 128) >= 200) return 4;
   if (N % 320 == 0 && g_nt_splitk) {
     const long tiles = tm * (N / 320);

@@ -62,7 +62,8 @@ int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* 
  * 2 force the 320x192x64 LDS-DMA wgrad kernel.  Returns DA_ERR_SHAPE for unknown keys. */
 int da_set_option(const char* key, int value);
 /* which kernel da_gemm_nt dispatches to for (M, N, K, Cin) given a split-K workspace of that many floats: 1 = gemm_nt_kernel (128x128 tile), 4 / 5 / 10 =
- * gemm_nt2_kernel with a 256x128 / 256x160 / 256x320 tile, 12 = the 16-wave 256x320 form (profiling labels only) */
+ * gemm_nt2_kernel with a 256x128 / 256x160 / 256x320 tile, 12 = the 16-wave 256x320 form, 14 = the 16-wave 256x256 form
+ * (profiling labels only) */
 int da_gemm_nt_variant_for(int M, int N, int K, int Cin, long splitk_ws_floats);
 
 /* dW[N][ksize*ksize*Cin] += sum_m dY[m][n] * gather(X)[m][k]   (fp32).

@@ -59,7 +59,7 @@ def test_downsampler_gather_mode(dev):
         assert _rel(got, ref) < 4e-3, (C, _rel(got, ref))
 
     run(2, 12, 12, 8, 72)
-    for variant in (0, 4, 5, 10, 12):
+    for variant in (0, 4, 5, 10, 12, 14):
         ops.set_option('gemm_nt_variant', variant)
         try:
             run(3, 12, 16, 64, 200)

@@ -4,7 +4,7 @@ bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (FETCH_SIZE is in KiB and under-re
 import csv, glob, json, re, sys, collections
 
 root = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/final'
-out = sys.argv[2] if len(sys.argv) > 2 else 'profiles/r01_pmc_hbm_traffic.json'
+out = sys.argv[2] if len(sys.argv) > 2 else 'profiles/r02_pmc_hbm_traffic.json'
 
 
 def short(name):
