@@ -259,16 +259,15 @@ static int g_nt_splitk = 1;  // da_set_option("gemm_nt_splitk", 0/1)  // 0 auto,
 // instantiation, forced only: two workgroups per CU stay phase-locked, so it gains <= 5 % on one K=320 shape class).  *splits > 1: split-K over
 // that many workgroups per tile (needs a workspace of splits*M*N floats) - used when the tile grid alone would
 // leave most of the 256 CUs idle (small M: low-resolution layers, small microbatches).
-static int pick_nt_variant(int M, int N, int K, int Cin, long ws_floats, int* splits) {
+static int g_nt_dispatch = 1;  // da_set_option("gemm_nt_dispatch", 0 legacy thresholds | 1 cost model)
+
+// legacy rule (round 1): largest tile whose grid still fills most of the 256 CUs, split-K only for the 256x320 form
+static int pick_nt_variant_legacy(int M, int N, int K, int Cin, long ws_floats, int* splits) {
   *splits = 1;
-  if (Cin % 64 != 0) return 1;
-  if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10 || g_nt_variant == 11 || g_nt_variant == 12 || g_nt_variant == 14) return g_nt_variant;
-  if (g_nt_variant != 0) return 1;
-  // one 512-thread workgroup per CU: pick the largest tile that still keeps most of the 256 CUs busy
   const long tm = (M + 255) / 256;
   if (N % 320 == 0 && tm * (N / 320) >= 160) return 12;
   if (N % 160 == 0 && tm * (N / 160) >= 200) return 5;
-  if (N % 256 == 0 && tm * (N / 256) >= 160) return 14;  // channel counts of the VAE encoder (256, 512): 16-wave 256 x 256 tile
+  if (N % 256 == 0 && tm * (N / 256) >= 160) return 14;
   if (N % 160 != 0 && tm * ((N + 127) / 128) >= 200) return 4;
   if (N % 320 == 0 && g_nt_splitk) {
     const long tiles = tm * (N / 320);
@@ -284,6 +283,44 @@ static int pick_nt_variant(int M, int N, int K, int Cin, long ws_floats, int* sp
   return 1;
 }
 
+// Cost model over (tile form, split-K factor).  One workgroup per CU, so a launch takes
+//   rounds(tiles * splits / 256 CUs) x (K-steps per split x step time + fixed prologue/epilogue) [+ split-K finalize].
+// Step / fixed times per form are measured (tools/opt_ab.py, microbatch 16 and 256): the 16-wave 256x320 form retires a
+// 64-deep step in ~1.5 us, the 8-wave 256x160 / 256x128 forms in ~1.1 us (latency-, not MFMA-bound), the 16-wave
+// 256x256 form in ~1.3 us.  At large M every form runs many rounds and the widest tile wins (as the legacy rule had
+// it); at small M (low-resolution levels, small microbatches) the legacy rule fell through to the 128x128 kernel -
+// 36 % of the step time at the reference YAML's microbatch 16 - where a half-empty grid of large tiles is 20-35 % faster.
+static int pick_nt_variant(int M, int N, int K, int Cin, long ws_floats, int* splits) {
+  *splits = 1;
+  if (Cin % 64 != 0) return 1;
+  if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10 || g_nt_variant == 11 || g_nt_variant == 12 || g_nt_variant == 14) return g_nt_variant;
+  if (g_nt_variant != 0) return 1;
+  if (!g_nt_dispatch) return pick_nt_variant_legacy(M, N, K, Cin, ws_floats, splits);
+  struct Form { int variant, bn; double step_us, fixed_us; };
+  static const Form forms[] = {{12, 320, 1.5, 8.0}, {14, 256, 1.3, 8.0}, {5, 160, 1.16, 6.0}, {4, 128, 1.07, 5.0}};
+  const long tm = (M + 255) / 256;
+  const int nk = K / 64;
+  double best = 1e30;
+  int best_v = 4, best_s = 1;
+  for (const Form& f : forms) {
+    const long tiles = tm * ((N + f.bn - 1) / f.bn);
+    for (int s = 1; s <= (g_nt_splitk ? 8 : 1); ++s) {
+      if (s > 1 && (nk / s < 4 || (long)s * M * N > ws_floats)) break;
+      const long rounds = (tiles * s + 255) / 256;
+      const int steps = (nk + s - 1) / s;
+      double t = (double)rounds * (steps * f.step_us + f.fixed_us);
+      if (s > 1) t += 20.0 + ((double)s * M * N * 4.0 + (double)M * N * 2.0) / 5.0e6;  // finalize launch + slab traffic at ~5 TB/s
+      if (t < best * 0.97) {  // ties go to the earlier (wider / unsplit) candidate
+        best = t;
+        best_v = f.variant;
+        best_s = s;
+      }
+    }
+  }
+  *splits = best_s;
+  return best_v;
+}
+
 extern "C" int da_gemm_nt_variant_for(int M, int N, int K, int Cin, long ws_floats) {
   int s;
   return pick_nt_variant(M, N, K, Cin, ws_floats, &s);
@@ -296,6 +333,10 @@ extern "C" int da_set_option(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_nt_splitk")) {
     g_nt_splitk = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_dispatch")) {
+    g_nt_dispatch = value;
     return DA_OK;
   }
   if (key && !strcmp(key, "gemm_nt_korder")) {

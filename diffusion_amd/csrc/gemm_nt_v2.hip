@@ -608,7 +608,7 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
   if (variant == 10) return launch_v2<8, 5, 2, 4, 64>(p, splits, ws, stream);
   if (variant == 11) return launch_v2<4, 10, 2, 2, 32>(p, 1, ws, stream);  // 128 x 320 x 32, 4 waves, 2 workgroups / CU
   if (variant == 12) return launch_v2<4, 5, 4, 4, 64>(p, splits, ws, stream);  // 256 x 320 x 64, 16 waves (4 / SIMD)
-  if (variant == 14) return launch_v2<4, 4, 4, 4, 64>(p, 1, ws, stream);       // 256 x 256 x 64, 16 waves: N = 256 / 512 (VAE encoder)
+  if (variant == 14) return launch_v2<4, 4, 4, 4, 64>(p, splits, ws, stream);      // 256 x 256 x 64, 16 waves: N = 256 / 512 (VAE encoder)
   return variant == 5 ? launch_v2<4, 5, 4, 2, 64>(p, splits, ws, stream) : launch_v2<4, 4, 4, 2, 64>(p, splits, ws, stream);
 }
 

@@ -284,6 +284,8 @@ class UNetHIP(nn.Module):
         self._scratch_key = None
         self.opt_step = 0
         self._grad_ready_cb = None  # parallel.BucketedAllReducer.ready during the last microbatch
+        import os
+        self.wgrad_stream = torch.cuda.Stream() if os.environ.get('DA_WGRAD_STREAM', '0') == '1' else None
         self._tape = None
         if init:
             self.reset_parameters(seed)
@@ -421,6 +423,9 @@ class UNetHIP(nn.Module):
         self._delta = torch.empty(B * max(cfg.attention_head_dim) * S * S, device=dev, dtype=F32)
         if ops.SPLITK_WS is None:  # 128 MiB fp32 slabs for split-K of small-M GEMMs (shared by all calls on the stream)
             ops.SPLITK_WS = torch.empty(32 * 1024 * 1024, device=dev, dtype=F32)
+        if self.wgrad_stream is not None:
+            self._wgrad_ws = torch.empty(32 * 1024 * 1024, device=dev, dtype=F32)
+            self._wgrad_scratch = torch.empty(need, device=dev, dtype=F32)
         self._scratch_key = key
 
     def _bf(self, m, c):
@@ -449,6 +454,29 @@ class UNetHIP(nn.Module):
         ops.groupnorm_bwd(x, dy, radd, dx, w.p, b.p, st, w.g, b.g, self._coef, self._scratch, B, HW, C, G, silu)
         return dx
 
+    def _wgrad(self, dy, x, gw, g, dbias=None, scratch=None):
+        """Weight (and bias) gradient of one layer.  Nothing on the backward critical path reads it, so with
+        ``wgrad_stream`` set it is issued on a second stream behind an event on its operands: the 256-workgroup wgrad grids
+        then share the chip with whatever the main stream runs next, and the HBM-bound links of the chain (norm / GEGLU /
+        short-K dgrad kernels, which cannot use the matrix pipes) stop costing wall time of their own."""
+        ws = self.wgrad_stream
+        if ws is None:
+            ops.gemm_tn_wgrad(dy, x, gw, g, dbias=dbias, scratch=scratch)
+            return
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        ws.wait_event(ev)
+        dy.record_stream(ws)   # the allocator must not hand these blocks out again before the side stream is done
+        x.record_stream(ws)
+        with torch.cuda.stream(ws):
+            old = ops.SPLITK_WS
+            ops.SPLITK_WS = self._wgrad_ws        # slab workspace of its own: the main stream's split-K GEMMs use the other
+            try:
+                ops.gemm_tn_wgrad(dy, x, gw, g, dbias=dbias, scratch=self._wgrad_scratch if scratch is not None else None)
+            finally:
+                ops.SPLITK_WS = old
+
     def _lin_fwd(self, x, key, out=None, bias=True, residual=None):
         m = self.M(key + '.weight')
         M = x.shape[0]
@@ -460,7 +488,7 @@ class UNetHIP(nn.Module):
         """grads of y = x W^T + b : accumulates dW, db; returns dx."""
         m = self.M(key + '.weight')
         M = x.shape[0]
-        ops.gemm_tn_wgrad(dy, x, m.gw, Geom.linear(M), dbias=self.V(key + '.bias').g if bias else None,
+        self._wgrad(dy, x, m.gw, Geom.linear(M), dbias=self.V(key + '.bias').g if bias else None,
                           scratch=self._scratch)
         if not need_dx:
             return None
@@ -499,21 +527,21 @@ class UNetHIP(nn.Module):
         conv1, conv2 = self.M(p + '.conv1.weight'), self.M(p + '.conv2.weight')
         cout, cin = conv1.N, conv1.C
         g3 = Geom.conv(B, H, W)
-        ops.gemm_tn_wgrad(dout, a2, conv2.gw, g3, dbias=self.V(p + '.conv2.bias').g, scratch=self._scratch)
+        self._wgrad(dout, a2, conv2.gw, g3, dbias=self.V(p + '.conv2.bias').g, scratch=self._scratch)
         da2 = self._bf(M, cout)
         ops.gemm_nt(dout, conv2.wt, da2, g3)
         dh1 = self._gn_bwd(h1, da2, None, p + '.norm2', st2, B, HW, 1)
         del da2
         to = self.tproj_offsets[p]
         ops.image_colsum(dh1, self._dtproj[:, to:to + cout], self.V(p + '.conv1.bias').g, self._scratch, B, HW)
-        ops.gemm_tn_wgrad(dh1, a1, conv1.gw, g3)
+        self._wgrad(dh1, a1, conv1.gw, g3)
         da1 = self._bf(M, cin)
         ops.gemm_nt(dh1, conv1.wt, da1, g3)
         del dh1
         if (p + '.conv_shortcut.weight') in self._mats:
             sm = self.M(p + '.conv_shortcut.weight')
             g1 = Geom.conv(B, H, W, 1)
-            ops.gemm_tn_wgrad(dout, x, sm.gw, g1, dbias=self.V(p + '.conv_shortcut.bias').g, scratch=self._scratch)
+            self._wgrad(dout, x, sm.gw, g1, dbias=self.V(p + '.conv_shortcut.bias').g, scratch=self._scratch)
             dxs = self._bf(M, cin)
             ops.gemm_nt(dout, sm.wt, dxs, g1)
         else:
@@ -598,7 +626,7 @@ class UNetHIP(nn.Module):
         dkv2 = self._bf(B * nk, 2 * C)
         ops.attn_bwd(q2, kv2[:, :C], kv2[:, C:], o2, do2, l2, self._delta, dq2, dkv2[:, :C], dkv2[:, C:], B, heads, HW,
                      nk, 0.125)
-        ops.gemm_tn_wgrad(dkv2, self._ctx, self.M(tb + '.attn2.kv.weight').gw, Geom.linear(B * nk))
+        self._wgrad(dkv2, self._ctx, self.M(tb + '.attn2.kv.weight').gw, Geom.linear(B * nk))
         dn2 = self._lin_bwd(n2, dq2, tb + '.attn2.to_q', bias=False)
         dh1 = self._ln_bwd(h1, dn2, dh2, tb + '.norm2', ln2)
         # self attention
@@ -607,7 +635,7 @@ class UNetHIP(nn.Module):
         ops.attn_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o1, do1, l1, self._delta, dqkv[:, :C],
                      dqkv[:, C:2 * C], dqkv[:, 2 * C:], B, heads, HW, HW, 0.125)
         mq = self.M(tb + '.attn1.qkv.weight')
-        ops.gemm_tn_wgrad(dqkv, n1, mq.gw, Geom.linear(M))
+        self._wgrad(dqkv, n1, mq.gw, Geom.linear(M))
         dn1 = self._bf(M, C)
         ops.gemm_nt(dqkv, mq.wt, dn1, Geom.linear(M))
         dh0 = self._ln_bwd(h0, dn1, dh1, tb + '.norm1', ln1)
@@ -742,7 +770,7 @@ class UNetHIP(nn.Module):
                 h, a, st, B, S = sv
                 m = self.M('conv_out.weight')
                 g3 = Geom.conv(B, S, S)
-                ops.gemm_tn_wgrad(dpred, a, m.gw, g3, dbias=self.V('conv_out.bias').g, scratch=self._scratch)
+                self._wgrad(dpred, a, m.gw, g3, dbias=self.V('conv_out.bias').g, scratch=self._scratch)
                 da = self._bf(B * S * S, m.C)
                 ops.gemm_nt(dpred, m.wt, da, g3)
                 dh = self._gn_bwd(h, da, None, 'conv_norm_out', st, B, S * S, 1)
@@ -756,7 +784,7 @@ class UNetHIP(nn.Module):
                 key, x, B, r = sv
                 lo = off(key + '.weight')
                 m = self.M(key + '.weight')
-                ops.gemm_tn_wgrad(dh, x, m.gw, Geom.up(B, r, r), dbias=self.V(key + '.bias').g, scratch=self._scratch)
+                self._wgrad(dh, x, m.gw, Geom.up(B, r, r), dbias=self.V(key + '.bias').g, scratch=self._scratch)
                 dup = self._bf(B * 4 * r * r, m.C)
                 ops.gemm_nt(dh, m.wt, dup, Geom.conv(B, 2 * r, 2 * r))
                 dx = self._bf(B * r * r, m.C)
@@ -775,7 +803,7 @@ class UNetHIP(nn.Module):
                 key, x, B, r = sv
                 lo = off(key + '.weight')
                 m = self.M(key + '.weight')
-                ops.gemm_tn_wgrad(dh, x, m.gw, Geom.down(B, r, r), dbias=self.V(key + '.bias').g, scratch=self._scratch)
+                self._wgrad(dh, x, m.gw, Geom.down(B, r, r), dbias=self.V(key + '.bias').g, scratch=self._scratch)
                 dx = self._bf(B * r * r, m.C)
                 ops.gemm_nt(dh, m.wt, dx, Geom.down_dgrad(B, r, r))
                 dh = dx
@@ -783,18 +811,20 @@ class UNetHIP(nn.Module):
                 xt8, B, S = sv
                 tot = self._bf(*dh.shape)
                 ops.add(dh, dskip.pop(0), tot)
-                ops.gemm_tn_wgrad(tot, xt8, self.M('conv_in.weight').gw, Geom.conv(B, S, S),
+                self._wgrad(tot, xt8, self.M('conv_in.weight').gw, Geom.conv(B, S, S),
                                   dbias=self.V('conv_in.bias').g, scratch=self._scratch)
                 lo = off('conv_in.weight')
             else:  # pragma: no cover
                 raise AssertionError(kind)
             if lo is not None and self._grad_ready_cb is not None:
+                if self.wgrad_stream is not None:   # "every gradient at offsets >= lo is final" includes the side stream's
+                    torch.cuda.current_stream().wait_stream(self.wgrad_stream)
                 self._grad_ready_cb(lo)
         # ---- timestep path
         te0, te1, te1s, temb, tembs = self._temb_saved
         Bt = te0.shape[0]
         mt = self.M('time_emb_proj_all.weight')
-        ops.gemm_tn_wgrad(self._dtproj, tembs, mt.gw, Geom.linear(Bt), dbias=self.V('time_emb_proj_all.bias').g,
+        self._wgrad(self._dtproj, tembs, mt.gw, Geom.linear(Bt), dbias=self.V('time_emb_proj_all.bias').g,
                           scratch=self._scratch)
         dtembs = self._bf(Bt, mt.C)
         ops.gemm_nt(self._dtproj, mt.wt, dtembs, Geom.linear(Bt))
@@ -804,6 +834,8 @@ class UNetHIP(nn.Module):
         dte1 = self._bf(*te1.shape)
         ops.silu_bwd(te1, dte1s, dte1)
         self._lin_bwd(te0, dte1, 'time_embedding.linear_1', need_dx=False)
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
         self._temb_saved = None
         self._cats = None
         self._tproj = None

@@ -198,3 +198,37 @@ def test_ddim_sampler_parity(dev, guidance):
                 pred = pu + guidance * (pt - pu)
             lat = sch.step(pred, t, lat)['prev_sample']
     assert _rel(lat.cpu(), ref) < 3e-2
+
+
+def test_wgrad_side_stream_gives_the_same_gradients(dev, monkeypatch):
+    """DA_WGRAD_STREAM=1 issues every weight-gradient GEMM on a second stream (event-ordered behind its operands, joined
+    before the optimizer): same launches, same arithmetic - the gradients must agree with the single-stream walk up to
+    the run-to-run order of the fp32 atomics behind the bias gradients."""
+    from diffusion_amd.models.models import stable_diffusion_2
+
+    def run(flag):
+        monkeypatch.setenv('DA_WGRAD_STREAM', flag)
+        model = stable_diffusion_2(model_name='tiny', pretrained=False, precomputed_latents=True, fsdp=False, seed=5)
+        assert (model.unet.wgrad_stream is not None) == (flag == '1')
+        g = torch.Generator().manual_seed(9)
+        B, S = 4, 16
+        batch = {'image_latents': torch.randn(B, 4, S, S, generator=g).to(dev),
+                 'caption_latents': torch.randn(B, 77, 128, generator=g).to(dev)}
+        t = torch.randint(0, 1000, (B,), generator=g).to(dev)
+        noise = torch.randn(B, 4, S, S, generator=g).to(dev)
+        grads = []
+        for _ in range(2):   # twice: the second pass reuses allocator blocks the first pass's side stream touched
+            model.unet.zero_grad()
+            out = model(batch, timesteps=t, noise=noise)
+            loss = model.loss(out, batch)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads.append(model.unet.grad.clone())
+        return loss.item(), grads
+
+    l0, g0 = run('0')
+    l1, g1 = run('1')
+    assert l0 == l1
+    for a, b in zip(g0, g1):
+        assert ((a - b).norm() / a.norm()).item() < 1e-5
+    assert ((g1[0] - g1[1]).norm() / g1[0].norm()).item() < 1e-5

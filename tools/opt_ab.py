@@ -31,7 +31,7 @@ if 'conv' in kinds:
     shapes += [(32, 320, 320, 3), (16, 640, 640, 3), (8, 1280, 1280, 3), (4, 1280, 1280, 3), (32, 960, 320, 3), (32, 640, 320, 3),
                (16, 1920, 640, 3), (16, 1280, 640, 3), (8, 2560, 1280, 3), (16, 320, 640, 3), (8, 640, 1280, 3)]
 if 'lin' in kinds:
-    for (h, c) in ((32, 320), (16, 640), (8, 1280)):
+    for (h, c) in ((32, 320), (16, 640), (8, 1280), (4, 1280)):
         shapes += [(h, c, c, 1), (h, 4 * c, c, 1), (h, c, 3 * c, 1)]
 
 
