@@ -175,7 +175,10 @@ int da_gemm_tn_v2_fast_period(int M, int N, int Hin, int Win, int Hout, int Wout
 int g_tn_variant = 0;  // 0 auto, 1 force v1 (128x128x32), 2 force v2 (320x192x64); da_set_option
 
 static bool tn_takes_v2(int M, int N, int Kt) {
-  const bool big = (M >= 4096) && (N >= 160) && (Kt >= 256);
+  // measured (tools/tn_ab.py, microbatch 16 / 64): the 320x192x64 kernel wins from 1,024 pixels up (1.1-2.3x), and at 256
+  // pixels once the gradient itself is large (N * K' >= 8 M elements: 1.2-1.5x; below that the 128x128x32 kernel is 1.4x
+  // faster)
+  const bool big = (N >= 160) && (Kt >= 256) && (M >= 1024 || (M >= 256 && (long)N * Kt >= (8L << 20)));
   return g_tn_variant == 2 || g_tn_variant == 3 || (g_tn_variant == 0 && big);
 }
 
