@@ -135,118 +135,117 @@ def build_layout(cfg: UNetConfig):
         pass
 
     self = _S()
-    if True:  # (indentation kept from the original method body)
-        fp = FlatParams()
-        boc = cfg.block_out_channels
-        temb = cfg.time_embed_dim
-        ctx = cfg.cross_attention_dim
-        self.resnet_names: List[Tuple[str, int, int]] = []  # (prefix, cin, cout) in forward order
-        self.tproj_offsets: Dict[str, int] = {}
+    fp = FlatParams()
+    boc = cfg.block_out_channels
+    temb = cfg.time_embed_dim
+    ctx = cfg.cross_attention_dim
+    self.resnet_names: List[Tuple[str, int, int]] = []  # (prefix, cin, cout) in forward order
+    self.tproj_offsets: Dict[str, int] = {}
 
-        def conv3(key, cout, cin, cout_pad=None, cin_pad=None):
-            co, ci = cout_pad or cout, cin_pad or cin
-            s = fp.add(key + '.weight', (co, 3, 3, ci), matrix_ntc=(co, 9, ci))
-            fp.view(key + '.weight', s, lambda t, cout=cout, cin=cin: t[:cout, :, :, :cin].permute(0, 3, 1, 2))
-            b = fp.add(key + '.bias', (co,))
-            fp.view(key + '.bias', b, lambda t, cout=cout: t[:cout])
+    def conv3(key, cout, cin, cout_pad=None, cin_pad=None):
+        co, ci = cout_pad or cout, cin_pad or cin
+        s = fp.add(key + '.weight', (co, 3, 3, ci), matrix_ntc=(co, 9, ci))
+        fp.view(key + '.weight', s, lambda t, cout=cout, cin=cin: t[:cout, :, :, :cin].permute(0, 3, 1, 2))
+        b = fp.add(key + '.bias', (co,))
+        fp.view(key + '.bias', b, lambda t, cout=cout: t[:cout])
 
-        def conv1(key, cout, cin):
-            s = fp.add(key + '.weight', (cout, cin), matrix_ntc=(cout, 1, cin))
-            fp.view(key + '.weight', s, lambda t: t[:, :, None, None])
+    def conv1(key, cout, cin):
+        s = fp.add(key + '.weight', (cout, cin), matrix_ntc=(cout, 1, cin))
+        fp.view(key + '.weight', s, lambda t: t[:, :, None, None])
+        b = fp.add(key + '.bias', (cout,))
+        fp.view(key + '.bias', b, lambda t: t)
+
+    def linear(key, cout, cin, bias=True):
+        s = fp.add(key + '.weight', (cout, cin), matrix_ntc=(cout, 1, cin))
+        fp.view(key + '.weight', s, lambda t: t)
+        if bias:
             b = fp.add(key + '.bias', (cout,))
             fp.view(key + '.bias', b, lambda t: t)
 
-        def linear(key, cout, cin, bias=True):
-            s = fp.add(key + '.weight', (cout, cin), matrix_ntc=(cout, 1, cin))
-            fp.view(key + '.weight', s, lambda t: t)
-            if bias:
-                b = fp.add(key + '.bias', (cout,))
-                fp.view(key + '.bias', b, lambda t: t)
+    def vecpair(key, c):
+        for k in ('weight', 'bias'):
+            s = fp.add(f'{key}.{k}', (c,))
+            fp.view(f'{key}.{k}', s, lambda t: t)
 
-        def vecpair(key, c):
-            for k in ('weight', 'bias'):
-                s = fp.add(f'{key}.{k}', (c,))
-                fp.view(f'{key}.{k}', s, lambda t: t)
+    # ---- enumerate resnets first (for the fused time_emb_proj matrix)
+    n = len(boc)
+    cin = boc[0]
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            self.resnet_names.append((f'down_blocks.{i}.resnets.{j}', cin if j == 0 else boc[i], boc[i]))
+        cin = boc[i]
+    self.resnet_names.append(('mid_block.resnets.0', boc[-1], boc[-1]))
+    self.resnet_names.append(('mid_block.resnets.1', boc[-1], boc[-1]))
+    for i in range(n):
+        for j in range(cfg.layers_per_block + 1):
+            cb, cs, co = up_block_resnet_channels(cfg, i, j)
+            self.resnet_names.append((f'up_blocks.{i}.resnets.{j}', cb + cs, co))
+    off = 0
+    for p, _, co in self.resnet_names:
+        self.tproj_offsets[p] = off
+        off += co
+    self.tproj_total = off
 
-        # ---- enumerate resnets first (for the fused time_emb_proj matrix)
-        n = len(boc)
-        cin = boc[0]
-        for i in range(n):
-            for j in range(cfg.layers_per_block):
-                self.resnet_names.append((f'down_blocks.{i}.resnets.{j}', cin if j == 0 else boc[i], boc[i]))
-            cin = boc[i]
-        self.resnet_names.append(('mid_block.resnets.0', boc[-1], boc[-1]))
-        self.resnet_names.append(('mid_block.resnets.1', boc[-1], boc[-1]))
-        for i in range(n):
-            for j in range(cfg.layers_per_block + 1):
-                cb, cs, co = up_block_resnet_channels(cfg, i, j)
-                self.resnet_names.append((f'up_blocks.{i}.resnets.{j}', cb + cs, co))
-        off = 0
-        for p, _, co in self.resnet_names:
-            self.tproj_offsets[p] = off
-            off += co
-        self.tproj_total = off
+    # ---- storages in forward order
+    linear('time_embedding.linear_1', temb, boc[0])
+    linear('time_embedding.linear_2', temb, temb)
+    s = fp.add('time_emb_proj_all.weight', (self.tproj_total, temb), matrix_ntc=(self.tproj_total, 1, temb))
+    b = fp.add('time_emb_proj_all.bias', (self.tproj_total,))
+    for p, _, co in self.resnet_names:
+        o = self.tproj_offsets[p]
+        fp.view(p + '.time_emb_proj.weight', s, lambda t, o=o, co=co: t[o:o + co])
+        fp.view(p + '.time_emb_proj.bias', b, lambda t, o=o, co=co: t[o:o + co])
+    conv3('conv_in', boc[0], cfg.in_channels, cin_pad=8)
 
-        # ---- storages in forward order
-        linear('time_embedding.linear_1', temb, boc[0])
-        linear('time_embedding.linear_2', temb, temb)
-        s = fp.add('time_emb_proj_all.weight', (self.tproj_total, temb), matrix_ntc=(self.tproj_total, 1, temb))
-        b = fp.add('time_emb_proj_all.bias', (self.tproj_total,))
-        for p, _, co in self.resnet_names:
-            o = self.tproj_offsets[p]
-            fp.view(p + '.time_emb_proj.weight', s, lambda t, o=o, co=co: t[o:o + co])
-            fp.view(p + '.time_emb_proj.bias', b, lambda t, o=o, co=co: t[o:o + co])
-        conv3('conv_in', boc[0], cfg.in_channels, cin_pad=8)
+    def resnet(p, cin, cout):
+        vecpair(p + '.norm1', cin)
+        conv3(p + '.conv1', cout, cin)
+        vecpair(p + '.norm2', cout)
+        conv3(p + '.conv2', cout, cout)
+        if cin != cout:
+            conv1(p + '.conv_shortcut', cout, cin)
 
-        def resnet(p, cin, cout):
-            vecpair(p + '.norm1', cin)
-            conv3(p + '.conv1', cout, cin)
-            vecpair(p + '.norm2', cout)
-            conv3(p + '.conv2', cout, cout)
-            if cin != cout:
-                conv1(p + '.conv_shortcut', cout, cin)
+    def transformer(p, c):
+        tb = p + '.transformer_blocks.0'
+        vecpair(p + '.norm', c)
+        linear(p + '.proj_in', c, c)
+        vecpair(tb + '.norm1', c)
+        s = fp.add(tb + '.attn1.qkv.weight', (3 * c, c), matrix_ntc=(3 * c, 1, c))
+        for idx, nm in enumerate(('to_q', 'to_k', 'to_v')):
+            fp.view(f'{tb}.attn1.{nm}.weight', s, lambda t, idx=idx, c=c: t[idx * c:(idx + 1) * c])
+        linear(tb + '.attn1.to_out.0', c, c)
+        vecpair(tb + '.norm2', c)
+        linear(tb + '.attn2.to_q', c, c, bias=False)
+        s = fp.add(tb + '.attn2.kv.weight', (2 * c, ctx), matrix_ntc=(2 * c, 1, ctx))
+        for idx, nm in enumerate(('to_k', 'to_v')):
+            fp.view(f'{tb}.attn2.{nm}.weight', s, lambda t, idx=idx, c=c: t[idx * c:(idx + 1) * c])
+        linear(tb + '.attn2.to_out.0', c, c)
+        vecpair(tb + '.norm3', c)
+        linear(tb + '.ff.net.0.proj', 8 * c, c)
+        linear(tb + '.ff.net.2', c, 4 * c)
+        linear(p + '.proj_out', c, c)
 
-        def transformer(p, c):
-            tb = p + '.transformer_blocks.0'
-            vecpair(p + '.norm', c)
-            linear(p + '.proj_in', c, c)
-            vecpair(tb + '.norm1', c)
-            s = fp.add(tb + '.attn1.qkv.weight', (3 * c, c), matrix_ntc=(3 * c, 1, c))
-            for idx, nm in enumerate(('to_q', 'to_k', 'to_v')):
-                fp.view(f'{tb}.attn1.{nm}.weight', s, lambda t, idx=idx, c=c: t[idx * c:(idx + 1) * c])
-            linear(tb + '.attn1.to_out.0', c, c)
-            vecpair(tb + '.norm2', c)
-            linear(tb + '.attn2.to_q', c, c, bias=False)
-            s = fp.add(tb + '.attn2.kv.weight', (2 * c, ctx), matrix_ntc=(2 * c, 1, ctx))
-            for idx, nm in enumerate(('to_k', 'to_v')):
-                fp.view(f'{tb}.attn2.{nm}.weight', s, lambda t, idx=idx, c=c: t[idx * c:(idx + 1) * c])
-            linear(tb + '.attn2.to_out.0', c, c)
-            vecpair(tb + '.norm3', c)
-            linear(tb + '.ff.net.0.proj', 8 * c, c)
-            linear(tb + '.ff.net.2', c, 4 * c)
-            linear(p + '.proj_out', c, c)
-
-        ri = iter(self.resnet_names)
-        for i in range(n):
-            for j in range(cfg.layers_per_block):
-                resnet(*next(ri))
-                if i < n - 1:
-                    transformer(f'down_blocks.{i}.attentions.{j}', boc[i])
+    ri = iter(self.resnet_names)
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            resnet(*next(ri))
             if i < n - 1:
-                conv3(f'down_blocks.{i}.downsamplers.0.conv', boc[i], boc[i])
-        resnet(*next(ri))
-        transformer('mid_block.attentions.0', boc[-1])
-        resnet(*next(ri))
-        rev = tuple(reversed(boc))
-        for i in range(n):
-            for j in range(cfg.layers_per_block + 1):
-                resnet(*next(ri))
-                if i > 0:
-                    transformer(f'up_blocks.{i}.attentions.{j}', rev[i])
-            if i < n - 1:
-                conv3(f'up_blocks.{i}.upsamplers.0.conv', rev[i], rev[i])
-        vecpair('conv_norm_out', boc[0])
-        conv3('conv_out', cfg.out_channels, boc[0], cout_pad=8)
+                transformer(f'down_blocks.{i}.attentions.{j}', boc[i])
+        if i < n - 1:
+            conv3(f'down_blocks.{i}.downsamplers.0.conv', boc[i], boc[i])
+    resnet(*next(ri))
+    transformer('mid_block.attentions.0', boc[-1])
+    resnet(*next(ri))
+    rev = tuple(reversed(boc))
+    for i in range(n):
+        for j in range(cfg.layers_per_block + 1):
+            resnet(*next(ri))
+            if i > 0:
+                transformer(f'up_blocks.{i}.attentions.{j}', rev[i])
+        if i < n - 1:
+            conv3(f'up_blocks.{i}.upsamplers.0.conv', rev[i], rev[i])
+    vecpair('conv_norm_out', boc[0])
+    conv3('conv_out', cfg.out_channels, boc[0], cout_pad=8)
     return fp, self.resnet_names, self.tproj_offsets, self.tproj_total
 
 
