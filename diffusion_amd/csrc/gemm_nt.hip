@@ -249,6 +249,7 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
 
 extern int g_tn_variant;  // gemm_tn.hip
 extern int g_nt_korder;  // gemm_nt_v2.hip
+extern int g_nt_persist;
 static int g_nt_variant = 0;
 static int g_nt_splitk = 1;  // da_set_option("gemm_nt_splitk", 0/1)  // 0 auto, 1 force v1 (128x128), 4 / 5 force v2 with BN 128 / 160 (when eligible)
 
@@ -337,6 +338,10 @@ extern "C" int da_set_option(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_nt_dispatch")) {
     g_nt_dispatch = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_persist")) {
+    g_nt_persist = value;
     return DA_OK;
   }
   if (key && !strcmp(key, "gemm_nt_korder")) {

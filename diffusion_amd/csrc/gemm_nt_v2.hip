@@ -17,6 +17,8 @@
 #include "diffusion_amd.h"
 
 
+int g_nt_persist = -1;  // da_set_option("gemm_nt_persist", n): resident workgroups of the persistent forms (-1 = #CUs, 0 = off)
+
 namespace {
 
 struct GemmNT2Params {
@@ -38,6 +40,7 @@ struct GemmNT2Params {
   bf16* G;                       // GEGLU variant: gated output [M][inner] (C then holds the pre-activation [M][2*inner])
   long ldg;
   int inner;                     // GEGLU variant: hidden width; W rows [0, inner) = value, [inner, 2*inner) = gate
+  int total_blocks;              // persistent (EARLY) form: tiles vblock = blockIdx.x, += gridDim.x, < total_blocks
   int korder;                    // 3x3 K-loop order: 0 = tap-major (k = tap*Cin + c, as W is laid out), 1 = channel-chunk-major
                                  // with the 9 taps innermost (see the K-loop comment)
 };
@@ -80,8 +83,8 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
 // EARLY: request the next stage at the START of the K-step instead of between its two MFMA halves.  Measured on the
 // 16-wave form: +3-4 % on 1x1 / linear shapes (A streamed from HBM, longer lead), -2-4 % on 3x3 convs (L2-resident taps;
 // the issue block delays the first MFMAs), so it is chosen by kernel size.
-template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU = 0, bool EARLY = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt2_kernel(GemmNT2Params p) {
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU, bool EARLY>
+DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
   constexpr int NW = WM * WN;
   constexpr int V2_BM = 16 * MT * WM, V2_BK = BK;
   static_assert((NW == 16 || NW == 8 || NW == 4) && (BK == 64 || BK == 32), "wave grid");
@@ -95,15 +98,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
   constexpr int B_BYTES = BN * V2_BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
   static_assert(V2_BM % (RG * NW) == 0, "A groups");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
   const int nblk = p.tiles_m * p.tiles_n;
-  const int split = blockIdx.x / nblk;  // splits of a tile are nblk workgroups apart
-  int bid = blockIdx.x - split * nblk;
+  const int split = vblock / nblk;  // splits of a tile are nblk workgroups apart
+  int bid = vblock - split * nblk;
   {
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
@@ -147,6 +149,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
     const int row = (wave * AJ + j) * RG + lrow;
     const int m = m0 + row;
     const bool mval = m < p.M;
+    if constexpr (EARLY) {  // EARLY is instantiated for ksize 1, mode 0 only: input pixel == output pixel, one tap
+      amask[j] = mval ? 1u : 0u;
+      abase[j] = p.A + (long)(mval ? m : 0) * p.lda + (lchunk ^ swz_key<BK>(row)) * 8;
+      continue;
+    }
     const int mm = mval ? m : 0;
     const int b = mm / HWo;
     const int rem = mm - b * HWo;
@@ -200,7 +207,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
     char* Bb = Ab + A_BYTES;
     const int r = tap / 3, s2 = tap - 3 * r;  // ksize 1: tap stays 0
     const unsigned tapbit = live ? (1u << tap) : 0u;
-    if constexpr (!UPS) {
+    if constexpr (EARLY) {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const void* src = (amask[j] & tapbit) ? (const void*)(abase[j] + c0) : (const void*)zero;
+        glds16(src, Ab + (wave * AJ + j) * 1024);
+      }
+    } else if constexpr (!UPS) {
       // tap displacement in source pixels: r, s (stride 1 / 2) or (r+pad)/2 (dgrad of stride 2, only even taps valid)
       const int dr = (r + (gshift ? pad : 0)) >> gshift, ds = (s2 + (gshift ? pad : 0)) >> gshift;
       const long soff = (long)(dr * p.Win + ds) * p.lda + c0;
@@ -248,13 +261,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
     const char* Ab = smem + stage * STAGE;
     const char* Bb = Ab + A_BYTES;
     bf16x8 a[MT], b[NT];
-    const int chunk = s * 4 + (lane >> 4);
+    // The fragment addresses are a handful of VALU ops from the lane id; they are recomputed per half-step (the empty asm
+    // stops the compiler from hoisting them out of the K loop).  Hoisted, they push the 128-VGPR body over the edge: a
+    // lane descriptor gets spilled, and its reload inside the K loop comes with an s_waitcnt vmcnt(0) - a wait for the
+    // LDS-DMA requests issued just before it - i.e. one exposed load latency per K-step (seen in the ISA of the 3x3 form
+    // after the K-order change, and of every form once the body sits in the persistent loop).
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int chunk = s * 4 + (ln >> 4);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
-      a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2<BK>(wm * (16 * MT) + i * 16 + (lane & 15), chunk));
+      a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2<BK>(wm * (16 * MT) + i * 16 + (ln & 15), chunk));
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      b[j] = *reinterpret_cast<const bf16x8*>(Bb + swz2<BK>(wn * (16 * NT) + j * 16 + (lane & 15), chunk));
+      b[j] = *reinterpret_cast<const bf16x8*>(Bb + swz2<BK>(wn * (16 * NT) + j * 16 + (ln & 15), chunk));
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -484,6 +504,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
   }
 }
 
+// The kernel.  Convolutions (EARLY == false): one tile per workgroup.  Linears and the fused GEGLU forms (EARLY == true,
+// short K: a 256 x 320 tile lasts ~25 us, most of it the store epilogue): a fixed grid of resident workgroups walks the
+// tile list with stride gridDim.x.  Between two tiles only the LDS traffic is fenced (lds_barrier), so the epilogue's
+// global stores stay in flight under the next tile's descriptor set-up and first DMA, and no workgroup is torn down and
+// re-dispatched per tile.
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU = 0, bool EARLY = false>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt2_kernel(GemmNT2Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (EARLY) {
+    for (int vb = blockIdx.x; vb < p.total_blocks; vb += gridDim.x) {  // one trip when gridDim.x == total_blocks
+      nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY>(p, vb, smem);
+      lds_barrier();  // everyone has left the epilogue's LDS strips before the next tile writes bias / stage 0
+    }
+  } else {
+    nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY>(p, blockIdx.x, smem);
+  }
+}
+
 // split-K finalize: out[m][n] = alpha * sum_s slab[s][m][n] + bias[n] + rowbias[image(m)][n] + R[m][n]
 __global__ void splitk_finalize_kernel(GemmNT2Params p, const float* ws) {
   const int nvec = p.N >> 3;
@@ -528,6 +566,21 @@ __global__ void splitk_finalize_kernel(GemmNT2Params p, const float* ws) {
   }
 }
 
+// grid of the persistent forms: one resident workgroup per CU (g_nt_persist overrides the CU count; 0 = one tile per
+// workgroup as in the convolution form)
+static int persistent_grid(int total_blocks) {
+  if (g_nt_persist == 0) return total_blocks;
+  int n = g_nt_persist;
+  if (n < 0) {
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return total_blocks;
+    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
+    n = cus[dev];
+  }
+  return total_blocks < n ? total_blocks : n;
+}
+
 template <int MT, int NT, int WM, int WN, int BK, bool UPS, bool EARLY>
 int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream) {
   GemmNT2Params p = p0;
@@ -544,10 +597,12 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
   p.ksteps_per_split = (nk_total + p.splits - 1) / p.splits;
   p.splits = (nk_total + p.ksteps_per_split - 1) / p.ksteps_per_split;  // no empty splits
   p.slab_stride = (long)p.M * p.N;
+  p.total_blocks = p.tiles_m * p.tiles_n * p.splits;
+  const int grid = EARLY ? persistent_grid(p.total_blocks) : p.total_blocks;
   if (p.splits > 1) {
     GemmNT2Params pk = p;
     pk.C = ws;  // partial slabs
-    hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(NTHREADS), SMEM,
+    hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY>), dim3(grid), dim3(NTHREADS), SMEM,
                        stream, pk);
     DA_CHECK_LAUNCH();
     const long total = (long)p.M * (p.N >> 3);
@@ -557,7 +612,7 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
     DA_CHECK_LAUNCH();
     return DA_OK;
   }
-  hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY>), dim3(p.tiles_m * p.tiles_n), dim3(NTHREADS), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY>), dim3(grid), dim3(NTHREADS), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -571,7 +626,8 @@ int launch_v2_geglu(GemmNT2Params p, hipStream_t stream) {
   p.ksteps_per_split = p.K / 64;
   static unsigned long long attr_done = 0;  // one bit per device
   if (da_ensure_dyn_smem((const void*)gemm_nt2_kernel<4, 5, 4, 4, 64, false, GM, true>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
-  hipLaunchKernelGGL((gemm_nt2_kernel<4, 5, 4, 4, 64, false, GM, true>), dim3(p.tiles_m * p.tiles_n), dim3(1024), SMEM, stream, p);
+  p.total_blocks = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL((gemm_nt2_kernel<4, 5, 4, 4, 64, false, GM, true>), dim3(persistent_grid(p.total_blocks)), dim3(1024), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -605,6 +661,7 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
   p.G = nullptr; p.ldg = 0; p.inner = 0;
   p.korder = g_nt_korder;
+  p.total_blocks = 0;
   if (variant == 10) return launch_v2<8, 5, 2, 4, 64>(p, splits, ws, stream);
   if (variant == 11) return launch_v2<4, 10, 2, 2, 32>(p, 1, ws, stream);  // 128 x 320 x 32, 4 waves, 2 workgroups / CU
   if (variant == 12) return launch_v2<4, 5, 4, 4, 64>(p, splits, ws, stream);  // 256 x 320 x 64, 16 waves (4 / SIMD)
@@ -627,7 +684,7 @@ extern "C" int da_gemm_nt_geglu(const void* A, long lda, const void* W, void* F,
   p.ksize = 1; p.mode = 0; p.out_fp32 = 0; p.alpha = 1.0f;
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
-  p.G = (bf16*)G; p.ldg = ldg; p.inner = inner; p.korder = 0;
+  p.G = (bf16*)G; p.ldg = ldg; p.inner = inner; p.korder = 0; p.total_blocks = 0;
   return launch_v2_geglu<1>(p, stream);
 }
 
@@ -646,6 +703,6 @@ extern "C" int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, c
   p.ksize = 1; p.mode = 0; p.out_fp32 = 0; p.alpha = 1.0f;
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
-  p.G = (bf16*)const_cast<void*>(F); p.ldg = ldf; p.inner = inner; p.korder = 0;
+  p.G = (bf16*)const_cast<void*>(F); p.ldg = ldf; p.inner = inner; p.korder = 0; p.total_blocks = 0;
   return launch_v2_geglu<2>(p, stream);
 }
