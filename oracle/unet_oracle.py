@@ -315,7 +315,10 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, x: Tensor, t: Tensor, c
             if i > 0:
                 h = transformer_2d(h, ctx, sd, f'up_blocks.{i}.attentions.{j}', rev_heads[i], cfg)
         if i < n - 1:
-            h = F.interpolate(h, scale_factor=2.0, mode='nearest')
+            # nearest-neighbour upsample to the NEXT skip's spatial size (diffusers passes ``upsample_size`` whenever the
+            # input side is not a multiple of 2^3, e.g. the 1x1 latent of the reference's own test, tests/test_model.py:18;
+            # otherwise this is the plain x2)
+            h = F.interpolate(h, size=tuple(skips[-1].shape[-2:]), mode='nearest')
             h = _conv(h, sd, f'up_blocks.{i}.upsamplers.0.conv')
     h = F.silu(_gn(h, sd, 'conv_norm_out', cfg.norm_num_groups, cfg.norm_eps))
     return _conv(h, sd, 'conv_out')
