@@ -63,6 +63,24 @@ DEVINL void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// Diagnostic build only (-DDA_STAMPS, tools/nt2_stamps.py): wave 0 of every workgroup writes the shader clock at the phase
+// boundaries of a tile, 16 slots per tile.
+#ifndef DA_RBUD16
+#define DA_RBUD16 6  // 16-byte registers of the residual ring on the 16-wave (128-VGPR) short-K forms: a two-strip ring
+#endif
+#ifdef DA_STAMPS
+__device__ unsigned long long* g_stamp_buf;
+#define STAMP(i)                                                                                      \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(long)vblock * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int da_debug_set_stamps(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 DEVINL void glds16(const void* gsrc, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -102,6 +120,17 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  // Epilogue work split: the WN waves of a row block share its 16-row strip as 64*WN (row, 8-column) tasks per pass.  The
+  // strip has 2.5 passes of tasks at BN 320 (1.25 for the GEGLU forward), and waves land on SIMD (wave % 4) = wn: with the
+  // ragged last pass always on wn 0.. the VALU-heavy epilogue (the strips measure VALU-issue bound: 2.0 us / strip with
+  // tight spread, 4 us with the gelu) ran 3 passes on SIMD 0/1 and 2 on SIMD 2/3.  The last pass's wave slot is rotated by
+  // the row block, so every SIMD gets the same share.
+  auto task_of = [&](int pss, int tasks) {
+    const bool ragged_last = (tasks % (64 * WN)) != 0 && pss == (tasks + 64 * WN - 1) / (64 * WN) - 1;
+    const int slot = ragged_last ? (wn + WN - wm % WN) % WN : wn;
+    return slot * 64 + lane + 64 * WN * pss;
+  };
+  STAMP(0);
 
   const int nblk = p.tiles_m * p.tiles_n;
   const int split = vblock / nblk;  // splits of a tile are nblk workgroups apart
@@ -282,8 +311,10 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   };
 
+  STAMP(1);
   issue(0, true);
   __syncthreads();
+  STAMP(2);
   for (int t = 0; t < nk; ++t) {
     // the address arithmetic + DMA issue of step t+1 sits BETWEEN the two MFMA halves of step t: every wave leaves
     // the barrier at the same time, so issuing first would idle the matrix pipe of all four SIMDs during it
@@ -301,6 +332,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
     }
     __syncthreads();  // vmcnt(0): step t+1 has landed; barrier: everyone is done reading stage t
   }
+  STAMP(3);
 
   if constexpr (GEGLU == 1) {
     static_assert(BN == 320 && !UPS, "GEGLU tile = 160 value + 160 gate columns");
@@ -320,7 +352,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
       lds_barrier();
 #pragma unroll
       for (int pss = 0; pss < GPASSES; ++pss) {
-        const int task = wn * 64 + lane + 64 * WN * pss;
+        const int task = task_of(pss, GTASKS);
         const int row = task / (HC / 8), c8 = (task - row * (HC / 8)) * 8;
         const int m = mrow0g + i * 16 + row;
         if (task < GTASKS && m < p.M && h0 + c8 < p.inner) {
@@ -346,6 +378,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
         }
       }
       lds_barrier();  // single strip buffer: everyone is done reading before it is rewritten
+      STAMP(4 + i);
     }
     return;
   }
@@ -362,7 +395,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
       bf16x8 fa[GPASSES], fg[GPASSES];  // this strip's saved value / gate rows, in flight across the LDS exchange
 #pragma unroll
       for (int pss = 0; pss < GPASSES; ++pss) {
-        const int task = wn * 64 + lane + 64 * WN * pss;
+        const int task = task_of(pss, GTASKS);
         const int row = task / CHB, c8 = (task - row * CHB) * 8;
         const int m = mrow0g + i * 16 + row;
         fa[pss] = zero8();
@@ -381,7 +414,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
       lds_barrier();
 #pragma unroll
       for (int pss = 0; pss < GPASSES; ++pss) {
-        const int task = wn * 64 + lane + 64 * WN * pss;
+        const int task = task_of(pss, GTASKS);
         const int row = task / CHB, c8 = (task - row * CHB) * 8;
         const int m = mrow0g + i * 16 + row;
         if (task < GTASKS && m < p.M && n0 + c8 < p.inner) {
@@ -402,6 +435,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
         }
       }
       lds_barrier();
+      STAMP(4 + i);
     }
     return;
   }
@@ -417,13 +451,13 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
   constexpr int PASSES = (TASKS + 64 * WN - 1) / (64 * WN);
   // residual rows are fetched RD strips ahead (the MFMA operand registers are dead by now): with a load -> wait ->
   // store chain per strip the epilogue exposed one HBM latency per strip, ~37 us per 256x320 tile on the K=320 linears
-  constexpr int RBUD = NW == 16 ? 3 : 10;  // 16-byte registers for the ring (128-VGPR waves get a one-strip ring)
+  constexpr int RBUD = NW == 16 ? (EARLY ? DA_RBUD16 : 3) : 10;  // 16-byte registers for the ring (128-VGPR waves get a one-strip ring)
   constexpr int RD = (MT < RBUD / PASSES) ? MT : (RBUD / PASSES < 1 ? 1 : RBUD / PASSES);
   int trow[PASSES], tcol[PASSES];
   bool tval[PASSES];
 #pragma unroll
   for (int pss = 0; pss < PASSES; ++pss) {
-    const int task = wn * 64 + lane + 64 * WN * pss;
+    const int task = task_of(pss, TASKS);
     trow[pss] = task / CH;
     tcol[pss] = (task - trow[pss] * CH) * 8;
     tval[pss] = task < TASKS && n0 + tcol[pss] < p.N;
@@ -501,6 +535,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
     }
     if (has_r && i + RD < MT) fetch_r(i + RD, i % RD);
     if (!EPI_DB) lds_barrier();  // single strip buffer: everyone is done reading before it is rewritten
+    STAMP(4 + i);
   }
 }
 
@@ -515,6 +550,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt
   if constexpr (EARLY) {
     for (int vb = blockIdx.x; vb < p.total_blocks; vb += gridDim.x) {  // one trip when gridDim.x == total_blocks
       nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY>(p, vb, smem);
+#ifdef DA_STAMPS
+      {
+        const int vblock = vb;
+        STAMP(12);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: how long the epilogue's stores take to drain
+        STAMP(13);
+      }
+#endif
       lds_barrier();  // everyone has left the epilogue's LDS strips before the next tile writes bias / stage 0
     }
   } else {
