@@ -65,9 +65,6 @@ DEVINL void lds_barrier() {
 
 // Diagnostic build only (-DDA_STAMPS, tools/nt2_stamps.py): wave 0 of every workgroup writes the shader clock at the phase
 // boundaries of a tile, 16 slots per tile.
-#ifndef DA_RBUD16
-#define DA_RBUD16 6  // 16-byte registers of the residual ring on the 16-wave (128-VGPR) short-K forms: a two-strip ring
-#endif
 #ifdef DA_STAMPS
 __device__ unsigned long long* g_stamp_buf;
 #define STAMP(i)                                                                                      \
@@ -102,7 +99,7 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
 // 16-wave form: +3-4 % on 1x1 / linear shapes (A streamed from HBM, longer lead), -2-4 % on 3x3 convs (L2-resident taps;
 // the issue block delays the first MFMAs), so it is chosen by kernel size.
 template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU, bool EARLY>
-DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
+DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   constexpr int NW = WM * WN;
   constexpr int V2_BM = 16 * MT * WM, V2_BK = BK;
   static_assert((NW == 16 || NW == 8 || NW == 4) && (BK == 64 || BK == 32), "wave grid");
@@ -116,6 +113,16 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
   constexpr int B_BYTES = BN * V2_BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
   static_assert(V2_BM % (RG * NW) == 0, "A groups");
+  // LDS map.  One tile per workgroup (convolutions): [stage 0 | stage 1 | bias row]; the epilogue's fp32 strips reuse the
+  // stage buffers.  Persistent short-K forms (EARLY): [stage 0 | stage 1 ... | bias row x 2] with the strips starting at
+  // stage 1 and running past it, clear of stage 0 - the NEXT tile's descriptors are set up and its first K-step is
+  // requested right after the K loop, so that load (2.2-2.8 us of a 27 us tile by the clock stamps, plus ~0.9 us of
+  // descriptor arithmetic waiting on nothing) is in flight under the epilogue instead of in front of the next K loop.
+  constexpr int EPI_LD = BN + 4;
+  constexpr int STRIP = 16 * EPI_LD;  // floats per 16-row strip
+  constexpr int STRIP_OFF = EARLY ? STAGE : 0;
+  constexpr int BIAS_OFF = !EARLY ? 2 * STAGE : (STAGE + WM * STRIP * 4 > 2 * STAGE ? STAGE + WM * STRIP * 4 : 2 * STAGE);
+  int vblock = vblock0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,23 +132,34 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
   // ragged last pass always on wn 0.. the VALU-heavy epilogue (the strips measure VALU-issue bound: 2.0 us / strip with
   // tight spread, 4 us with the gelu) ran 3 passes on SIMD 0/1 and 2 on SIMD 2/3.  The last pass's wave slot is rotated by
   // the row block, so every SIMD gets the same share.
-  auto task_of = [&](int pss, int tasks) {
+  auto task_of = [&](int ln, int pss, int tasks) {
     const bool ragged_last = (tasks % (64 * WN)) != 0 && pss == (tasks + 64 * WN - 1) / (64 * WN) - 1;
     const int slot = ragged_last ? (wn + WN - wm % WN) % WN : wn;
-    return slot * 64 + lane + 64 * WN * pss;
+    return slot * 64 + ln + 64 * WN * pss;
+  };
+  // Per-lane values derived from the lane id inside the tile loop of the persistent forms would be hoisted out of it and
+  // kept in VGPRs across the K loop, which has none to spare (128 per wave): each phase starts from a laundered copy, so
+  // its lane-derived constants are recomputed per tile (a few VALU ops) instead of living - or spilling - through the loop.
+  auto fresh_lane = [&]() {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    return ln;
   };
   STAMP(0);
 
   const int nblk = p.tiles_m * p.tiles_n;
-  const int split = vblock / nblk;  // splits of a tile are nblk workgroups apart
-  int bid = vblock - split * nblk;
-  {
+  int split, tn, m0, n0;  // the tile the DMA descriptors below belong to (wave-uniform)
+  auto locate = [&](int vb) {
+    split = vb / nblk;  // splits of a tile are nblk workgroups apart
+    int bid = vb - split * nblk;
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
-  const int m0 = tm * V2_BM, n0 = tn * BN;
+    const int tm = bid / p.tiles_n;
+    tn = bid - tm * p.tiles_n;
+    m0 = tm * V2_BM;
+    n0 = tn * BN;
+  };
   // weight / bias row behind tile column c (GEGLU: 160 value rows, then the 160 matching gate rows)
   auto wrow = [&](int c) {
     if constexpr (GEGLU == 1) return c < BN / 2 ? tn * (BN / 2) + c : p.inner + tn * (BN / 2) + (c - BN / 2);
@@ -155,12 +173,14 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
   const int hlim = gshift ? 2 * p.Hin : p.Hin, wlim = gshift ? 2 * p.Win : p.Win;
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   // bias for this column block -> LDS (behind the stage buffers), read back in the epilogue; zeros when absent
-  if (tid < BN / 4) {
-    const int n = wrow(tid * 4);
-    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-    *reinterpret_cast<f32x4*>(smem + 2 * STAGE + tid * 16) = bv;
-  }
+  // (LDS-DMA, like the tiles: no register round trip, no wait here - it has landed by the next __syncthreads)
+  auto load_bias = [&](int buf) {
+    if (tid < BN / 4) {
+      const int n = wrow(tid * 4);
+      const void* src = (p.bias && n < p.N) ? (const void*)(p.bias + n) : (const void*)zero;
+      glds16(src, smem + BIAS_OFF + buf * (BN * 4) + wave * 1024);
+    }
+  };
 
   // ---- per-lane DMA sources, reduced ONCE per tile to what a K-step needs: the address arithmetic of a step runs on
   // every wave with the matrix pipe idle (it measured ~0.45 us of a ~2.2 us step when done from scratch each time).
@@ -169,18 +189,28 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
   //   amask[j]  bit t: tap t reads inside the image (modes: 0 stride 1, 1 stride 2, 2 dgrad of stride 2, 3 fused
   //             nearest-2x upsample); bits 16/17: parity of the output row / column (mode 3 only)
   // so that a step adds one wave-uniform offset (tap displacement + channel offset) and selects the zero page.
-  const int lrow = lane / LR, lchunk = lane % LR;
   const int ntaps = p.ksize * p.ksize;
   const bf16* abase[AJ];
   unsigned amask[AJ];
+  unsigned aoff[AJ];  // EARLY forms only
+  unsigned woff[BJ];  // bytes
+  int nk, tap, c0;
+  const int nk_total = p.K / V2_BK;
+  const bool tap_inner = p.korder != 0 && ntaps > 1;  // K-loop order, see below
+  auto describe = [&]() {
+  const int dl = fresh_lane();
+  const int lrow = dl / LR, lchunk = dl % LR;
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int row = (wave * AJ + j) * RG + lrow;
     const int m = m0 + row;
     const bool mval = m < p.M;
-    if constexpr (EARLY) {  // EARLY is instantiated for ksize 1, mode 0 only: input pixel == output pixel, one tap
-      amask[j] = mval ? 1u : 0u;
-      abase[j] = p.A + (long)(mval ? m : 0) * p.lda + (lchunk ^ swz_key<BK>(row)) * 8;
+    if constexpr (EARLY) {
+      // EARLY is instantiated for ksize 1, mode 0 only: input pixel == output pixel, one tap.  The source is the uniform
+      // base A + c0 plus a 32-bit per-lane BYTE offset (the host checks M * lda * 2 < 4 GiB), the SGPR-base addressing form
+      // of the load: one VGPR per row group instead of a 64-bit pointer and a mask.  Rows past M read row 0: their
+      // products land in rows the epilogue never stores.
+      aoff[j] = (unsigned)(mval ? m : 0) * (unsigned)(p.lda * 2) + (lchunk ^ swz_key<BK>(row)) * 16;
       continue;
     }
     const int mm = mval ? m : 0;
@@ -201,26 +231,22 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
   }
   // B: row groups wave, wave+NW, ... (< BGROUPS): uniform base W + k0 plus a constant per-lane element offset.
   // Rows past N are clamped (their products land in columns the epilogue never stores).
-  unsigned woff[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     const int g = wave + NW * j;
     const int row = g * RG + lrow;
     const int n = min(wrow(row), p.N - 1);
-    woff[j] = (unsigned)n * (unsigned)p.K + (lchunk ^ swz_key<BK>(row)) * 8;
+    woff[j] = ((unsigned)n * (unsigned)p.K + (lchunk ^ swz_key<BK>(row)) * 8) * 2;
   }
 
   const int kstep_begin = split * p.ksteps_per_split;
-  const int nk_total = p.K / V2_BK;
-  const int nk = min(p.ksteps_per_split, nk_total - kstep_begin);
+  nk = min(p.ksteps_per_split, nk_total - kstep_begin);
   // K-loop order.  W is [n][tap][c], and walking k linearly visits tap 0 of all Cin channels, then tap 1, ...: the 9
   // shifted reads of one activation row are Cin/64 steps apart, and with every CU of an XCD streaming its own row block
   // (32 x Cin/64 x 32 KiB between two taps) they fall out of the 4 MiB L2: 1.68 GB of fabric reads per launch on the
   // 320-channel 32x32 layers where 0.34 GB is algorithmic (rocprofv3 FETCH_SIZE, L2 hit 58 %).  korder 1 walks one
   // 64-channel chunk through its 9 taps before the next chunk: the re-reads are consecutive steps over a ~42 KiB footprint.
   // Same products, summed in a different order.
-  const bool tap_inner = p.korder != 0 && ntaps > 1;
-  int tap, c0;
   if (tap_inner) {
     const int ch = kstep_begin / ntaps;
     tap = kstep_begin - ch * ntaps;
@@ -230,6 +256,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
     tap = kb / p.Cin;
     c0 = kb - tap * p.Cin;
   }
+  };  // describe()
   // live == false (the step after the last): A reads the zero page, B re-reads K-step 0 - no branch in the K loop
   auto issue = [&](int stage, bool live) {
     char* Ab = smem + stage * STAGE;
@@ -237,11 +264,9 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
     const int r = tap / 3, s2 = tap - 3 * r;  // ksize 1: tap stays 0
     const unsigned tapbit = live ? (1u << tap) : 0u;
     if constexpr (EARLY) {
+      const char* au = reinterpret_cast<const char*>(p.A + (live ? c0 : 0));  // the step after the last re-reads K-step 0
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) {
-        const void* src = (amask[j] & tapbit) ? (const void*)(abase[j] + c0) : (const void*)zero;
-        glds16(src, Ab + (wave * AJ + j) * 1024);
-      }
+      for (int j = 0; j < AJ; ++j) glds16(au + aoff[j], Ab + (wave * AJ + j) * 1024);
     } else if constexpr (!UPS) {
       // tap displacement in source pixels: r, s (stride 1 / 2) or (r+pad)/2 (dgrad of stride 2, only even taps valid)
       const int dr = (r + (gshift ? pad : 0)) >> gshift, ds = (s2 + (gshift ? pad : 0)) >> gshift;
@@ -262,7 +287,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
         glds16(src, Ab + (wave * AJ + j) * 1024);
       }
     }
-    const bf16* wb = p.W + (live ? tap * p.Cin + c0 : 0);
+    const char* wb = reinterpret_cast<const char*>(p.W + (live ? tap * p.Cin + c0 : 0));
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       const int g = wave + NW * j;
@@ -281,10 +306,6 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
   };
 
   f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto compute_half = [&](int stage, int s) {
     const char* Ab = smem + stage * STAGE;
@@ -311,10 +332,24 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   };
 
+  // stage 0 of the described tile has been requested; returns with the tile's products in acc and both stages idle
+  // The accumulators start from the bias (plain forms with alpha == 1 and no split-K: the sum is the same up to fp32
+  // rounding order): the epilogue's passes then need neither the 2 x 16-B LDS reads of the bias row per task - as much
+  // LDS traffic as reading the strip itself - nor the registers to hold them next to the residual ring.
+  const bool fold_bias = p.alpha == 1.0f && p.splits == 1;  // (the GEGLU entry points always launch with alpha 1, one split)
+  auto kloop = [&](const int bbuf) {
   STAMP(1);
-  issue(0, true);
   __syncthreads();
   STAMP(2);
+  {
+    const float* brow = reinterpret_cast<const float*>(smem + BIAS_OFF + bbuf * (BN * 4)) + wn * (16 * NT) + (fresh_lane() & 15);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float b = fold_bias ? brow[j * 16] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][j] = f32x4{b, b, b, b};
+    }
+  }
   for (int t = 0; t < nk; ++t) {
     // the address arithmetic + DMA issue of step t+1 sits BETWEEN the two MFMA halves of step t: every wave leaves
     // the barrier at the same time, so issuing first would idle the matrix pipe of all four SIMDs during it
@@ -333,26 +368,31 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
     __syncthreads();  // vmcnt(0): step t+1 has landed; barrier: everyone is done reading stage t
   }
   STAMP(3);
+  };  // kloop()
 
+  // the epilogue of tile (m0e, n0e, tne, splite) with its bias row in LDS buffer bbuf
+  auto epilogue = [&](const int m0e, const int n0e, const int tne, const int splite, const int bbuf) {
+  const float* bias_lds = reinterpret_cast<const float*>(smem + BIAS_OFF + bbuf * (BN * 4));
+  float* const strips = reinterpret_cast<float*>(smem + STRIP_OFF);
+  const int el = fresh_lane();
   if constexpr (GEGLU == 1) {
     static_assert(BN == 320 && !UPS, "GEGLU tile = 160 value + 160 gate columns");
     constexpr int GLD = BN + 4, GSTRIP = 16 * GLD, HC = BN / 2;  // strip layout as below; HC hidden units per tile
     constexpr int GTASKS = 16 * (HC / 8), GPASSES = (GTASKS + 64 * WN - 1) / (64 * WN);
-    const float* bl = reinterpret_cast<const float*>(smem + 2 * STAGE);
-    const int mrow0g = m0 + wm * (16 * MT);
-    const int h0 = tn * HC;
+    const int mrow0g = m0e + wm * (16 * MT);
+    const int h0 = tne * HC;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      float* ew = reinterpret_cast<float*>(smem) + wm * GSTRIP;
+      float* ew = strips + wm * GSTRIP;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          ew[((lane >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (lane & 15)] = acc[i][j][e];
+          ew[((el >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (el & 15)] = acc[i][j][e];
       lds_barrier();
 #pragma unroll
       for (int pss = 0; pss < GPASSES; ++pss) {
-        const int task = task_of(pss, GTASKS);
+        const int task = task_of(el, pss, GTASKS);
         const int row = task / (HC / 8), c8 = (task - row * (HC / 8)) * 8;
         const int m = mrow0g + i * 16 + row;
         if (task < GTASKS && m < p.M && h0 + c8 < p.inner) {
@@ -361,13 +401,12 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
           for (int q4 = 0; q4 < 2; ++q4) {
             const f32x4 v4 = *reinterpret_cast<const f32x4*>(&ew[row * GLD + c8 + 4 * q4]);
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(&ew[row * GLD + HC + c8 + 4 * q4]);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bl + c8 + 4 * q4);
-            const f32x4 bg = *reinterpret_cast<const f32x4*>(bl + HC + c8 + 4 * q4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              // rounded to bf16 BEFORE gating, exactly as the two-kernel path (da_gemm_nt then da_geglu_fwd) does
-              fv[4 * q4 + e] = f2bf(v4[e] * p.alpha + bv[e]);
-              fg[4 * q4 + e] = f2bf(g4[e] * p.alpha + bg[e]);
+              // (bias: in the accumulators from the start, as in the plain form) rounded to bf16 BEFORE gating, exactly as
+              // the two-kernel path (da_gemm_nt then da_geglu_fwd) does
+              fv[4 * q4 + e] = f2bf(v4[e]);
+              fg[4 * q4 + e] = f2bf(g4[e]);
               og[4 * q4 + e] = f2bf(bf2f(fv[4 * q4 + e]) * gelu_f(bf2f(fg[4 * q4 + e])));
             }
           }
@@ -388,20 +427,20 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
     // d(gated); arithmetic and rounding points as da_geglu_bwd on a bf16 d(gated)
     constexpr int GLD = BN + 4, GSTRIP = 16 * GLD, CHB = BN / 8;
     constexpr int GTASKS = 16 * CHB, GPASSES = (GTASKS + 64 * WN - 1) / (64 * WN);
-    const int mrow0g = m0 + wm * (16 * MT);
+    const int mrow0g = m0e + wm * (16 * MT);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      float* ew = reinterpret_cast<float*>(smem) + wm * GSTRIP;
+      float* ew = strips + wm * GSTRIP;
       bf16x8 fa[GPASSES], fg[GPASSES];  // this strip's saved value / gate rows, in flight across the LDS exchange
 #pragma unroll
       for (int pss = 0; pss < GPASSES; ++pss) {
-        const int task = task_of(pss, GTASKS);
+        const int task = task_of(el, pss, GTASKS);
         const int row = task / CHB, c8 = (task - row * CHB) * 8;
         const int m = mrow0g + i * 16 + row;
         fa[pss] = zero8();
         fg[pss] = zero8();
-        if (task < GTASKS && m < p.M && n0 + c8 < p.inner) {
-          const bf16* fp = p.G + (long)m * p.ldg + n0 + c8;
+        if (task < GTASKS && m < p.M && n0e + c8 < p.inner) {
+          const bf16* fp = p.G + (long)m * p.ldg + n0e + c8;
           fa[pss] = ld8(fp);
           fg[pss] = ld8(fp + p.inner);
         }
@@ -410,14 +449,14 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          ew[((lane >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (lane & 15)] = acc[i][j][e];
+          ew[((el >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (el & 15)] = acc[i][j][e];
       lds_barrier();
 #pragma unroll
       for (int pss = 0; pss < GPASSES; ++pss) {
-        const int task = task_of(pss, GTASKS);
+        const int task = task_of(el, pss, GTASKS);
         const int row = task / CHB, c8 = (task - row * CHB) * 8;
         const int m = mrow0g + i * 16 + row;
-        if (task < GTASKS && m < p.M && n0 + c8 < p.inner) {
+        if (task < GTASKS && m < p.M && n0e + c8 < p.inner) {
           bf16x8 da, dg;
 #pragma unroll
           for (int q4 = 0; q4 < 2; ++q4) {
@@ -429,7 +468,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
               dg[4 * q4 + e] = f2bf(df * bf2f(fa[pss][4 * q4 + e]) * dgelu_f(gf));
             }
           }
-          bf16* op = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n0 + c8;
+          bf16* op = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n0e + c8;
           st8(op, da);
           st8(op + p.inner, dg);
         }
@@ -443,33 +482,37 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
   // ---- epilogue: the WN waves that share a row block stage their i-th 16-row MFMA strip side by side in LDS, then
   // leave it as full BN-wide rows (640 B contiguous per row at BN 320) - per-wave strips would store and read the
   // residual in 16*NT*2-byte pieces (160 B, straddling 128-B lines), which measured ~2.4 TB/s on the K=320 linears
-  constexpr int EPI_LD = BN + 4;
-  constexpr int STRIP = 16 * EPI_LD;                      // floats per 16-row strip
-  constexpr bool EPI_DB = 2 * WM * STRIP * 4 <= 2 * STAGE;  // double-buffered strips: one barrier per strip
+  constexpr bool EPI_DB = !EARLY && 2 * WM * STRIP * 4 <= 2 * STAGE;  // double-buffered strips: one barrier per strip
   constexpr int CH = BN / 8;                              // 8-column chunks per row
   constexpr int TASKS = 16 * CH;                          // (row, chunk) pairs per strip, shared by 64*WN lanes
   constexpr int PASSES = (TASKS + 64 * WN - 1) / (64 * WN);
-  // residual rows are fetched RD strips ahead (the MFMA operand registers are dead by now): with a load -> wait ->
-  // store chain per strip the epilogue exposed one HBM latency per strip, ~37 us per 256x320 tile on the K=320 linears
-  constexpr int RBUD = NW == 16 ? (EARLY ? DA_RBUD16 : 3) : 10;  // 16-byte registers for the ring (128-VGPR waves get a one-strip ring)
+  // residual rows are fetched ahead of their strip (the MFMA operand registers are dead by now): with a load -> wait ->
+  // store chain per strip the epilogue exposed one HBM latency per strip, ~37 us per 256x320 tile on the K=320 linears.
+  // 8-wave forms: a ring RD strips deep, refilled after a strip's stores; the 16-wave forms (128 VGPRs) have room for ONE
+  // strip of residual next to the accumulators, and ~1.6 us of each strip's load stays exposed.  Two things that did not
+  // fix that (clock stamps, tools/nt2_stamps.py): a two-strip ring spills - the spill of a just-requested register waits
+  // for its load - and refilling each register right after its use (same footprint, a full strip of lead) makes the
+  // compiler's s_waitcnt conservative: with the validity branches around every load it cannot count the requests issued
+  // since, waits vmcnt(0) before each use, and the strips got 20 % slower.
+  constexpr int RBUD = NW == 16 ? 3 : 10;  // 16-byte registers for the ring
   constexpr int RD = (MT < RBUD / PASSES) ? MT : (RBUD / PASSES < 1 ? 1 : RBUD / PASSES);
   int trow[PASSES], tcol[PASSES];
   bool tval[PASSES];
 #pragma unroll
   for (int pss = 0; pss < PASSES; ++pss) {
-    const int task = task_of(pss, TASKS);
+    const int task = task_of(el, pss, TASKS);
     trow[pss] = task / CH;
     tcol[pss] = (task - trow[pss] * CH) * 8;
-    tval[pss] = task < TASKS && n0 + tcol[pss] < p.N;
+    tval[pss] = task < TASKS && n0e + tcol[pss] < p.N;
   }
-  const int mrow0 = m0 + wm * (16 * MT);
+  const int mrow0 = m0e + wm * (16 * MT);
   const bool has_r = p.R != nullptr && p.splits == 1;
   bf16x8 rres[RD][PASSES];
   auto fetch_r = [&](int i, int slot) {
 #pragma unroll
     for (int pss = 0; pss < PASSES; ++pss) {
       const int m = mrow0 + i * 16 + trow[pss];
-      if (tval[pss] && m < p.M) rres[slot][pss] = ld8(p.R + (long)m * p.ldr + n0 + tcol[pss]);
+      if (tval[pss] && m < p.M) rres[slot][pss] = ld8(p.R + (long)m * p.ldr + n0e + tcol[pss]);
     }
   };
 #pragma unroll
@@ -478,37 +521,44 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
     for (int pss = 0; pss < PASSES; ++pss) rres[i][pss] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     if (has_r) fetch_r(i, i);
   }
-  const float* bias_lds = reinterpret_cast<const float*>(smem + 2 * STAGE);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    float* ew = reinterpret_cast<float*>(smem) + ((EPI_DB ? (i & 1) * WM : 0) + wm) * STRIP;
+    float* ew = strips + ((EPI_DB ? (i & 1) * WM : 0) + wm) * STRIP;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        ew[((lane >> 4) * 4 + e) * EPI_LD + wn * (16 * NT) + j * 16 + (lane & 15)] = acc[i][j][e];
+        ew[((el >> 4) * 4 + e) * EPI_LD + wn * (16 * NT) + j * 16 + (el & 15)] = acc[i][j][e];
     lds_barrier();
 #pragma unroll
     for (int pss = 0; pss < PASSES; ++pss) {
       const int row = trow[pss], col8 = tcol[pss];
       const int m = mrow0 + i * 16 + row;
-      const int n = n0 + col8;
+      const int n = n0e + col8;
       if (tval[pss] && m < p.M) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8]);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8 + 4]);
         if (p.splits > 1) {  // split-K partial: raw fp32 sums into this split's slab; finalize kernel does the epilogue
-          float* cp = reinterpret_cast<float*>(p.C) + split * p.slab_stride + (long)m * p.N + n;
+          float* cp = reinterpret_cast<float*>(p.C) + splite * p.slab_stride + (long)m * p.N + n;
           *reinterpret_cast<f32x4*>(cp) = v0;
           *reinterpret_cast<f32x4*>(cp + 4) = v1;
           continue;
         }
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_lds + col8);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_lds + col8 + 4);
         float v[8];
+        if (fold_bias) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = v0[e] * p.alpha + b0[e];
-          v[e + 4] = v1[e] * p.alpha + b1[e];
+          for (int e = 0; e < 4; ++e) {
+            v[e] = v0[e];
+            v[e + 4] = v1[e];
+          }
+        } else {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_lds + col8);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_lds + col8 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = v0[e] * p.alpha + b0[e];
+            v[e + 4] = v1[e] * p.alpha + b1[e];
+          }
         }
         if (p.rowbias) {
           const int b = m / HWo;
@@ -537,32 +587,46 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock, char* smem) {
     if (!EPI_DB) lds_barrier();  // single strip buffer: everyone is done reading before it is rewritten
     STAMP(4 + i);
   }
+  };  // epilogue()
+
+  locate(vblock);
+  load_bias(0);
+  describe();
+  issue(0, true);
+  if constexpr (!EARLY) {
+    kloop(0);
+    epilogue(m0, n0, tn, split, 0);
+  } else {
+    // a fixed grid of resident workgroups walks the tile list with stride gridDim.x
+    for (int bbuf = 0;; bbuf ^= 1) {
+      kloop(bbuf);
+      const int m0e = m0, n0e = n0, tne = tn, splite = split;
+      const int vnext = vblock + (int)gridDim.x;
+      const bool more = vnext < p.total_blocks;
+      if (more) {  // wave-uniform
+        locate(vnext);
+        load_bias(bbuf ^ 1);
+        describe();
+        issue(0, true);
+      }
+      STAMP(8);
+      epilogue(m0e, n0e, tne, splite, bbuf);
+      STAMP(12);
+      if (!more) break;
+      vblock = vnext;  // the next kloop() opens with __syncthreads: every wave has left the strips, stage 0 has landed
+    }
+  }
 }
 
 // The kernel.  Convolutions (EARLY == false): one tile per workgroup.  Linears and the fused GEGLU forms (EARLY == true,
-// short K: a 256 x 320 tile lasts ~25 us, most of it the store epilogue): a fixed grid of resident workgroups walks the
-// tile list with stride gridDim.x.  Between two tiles only the LDS traffic is fenced (lds_barrier), so the epilogue's
-// global stores stay in flight under the next tile's descriptor set-up and first DMA, and no workgroup is torn down and
+// short K: a 256 x 320 tile lasts ~25 us, half of it the epilogue): a fixed grid of resident workgroups walks the tile
+// list with stride gridDim.x inside nt2_tile, requesting the next tile's first K-step before the epilogue of the current
+// one, so neither that load nor the epilogue's stores are waited for between tiles, and no workgroup is torn down and
 // re-dispatched per tile.
 template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU = 0, bool EARLY = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt2_kernel(GemmNT2Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if constexpr (EARLY) {
-    for (int vb = blockIdx.x; vb < p.total_blocks; vb += gridDim.x) {  // one trip when gridDim.x == total_blocks
-      nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY>(p, vb, smem);
-#ifdef DA_STAMPS
-      {
-        const int vblock = vb;
-        STAMP(12);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: how long the epilogue's stores take to drain
-        STAMP(13);
-      }
-#endif
-      lds_barrier();  // everyone has left the epilogue's LDS strips before the next tile writes bias / stage 0
-    }
-  } else {
-    nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY>(p, blockIdx.x, smem);
-  }
+  nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY>(p, blockIdx.x, smem);
 }
 
 // split-K finalize: out[m][n] = alpha * sum_s slab[s][m][n] + bias[n] + rowbias[image(m)][n] + R[m][n]
@@ -629,8 +693,10 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
   GemmNT2Params p = p0;
   constexpr int V2_BM = 16 * MT * WM, V2_BK = BK, NTHREADS = 64 * WM * WN;
   constexpr int BN = 16 * NT * WN;
-  constexpr int SMEM = 2 * (V2_BM * V2_BK * 2 + BN * V2_BK * 2) + BN * 4;  // 2 stages + bias
-  static_assert(SMEM - BN * 4 >= WM * 16 * (BN + 4) * 4, "epilogue strips fit in the stage buffers");
+  constexpr int STAGE = V2_BM * V2_BK * 2 + BN * V2_BK * 2, STRIPS = WM * 16 * (BN + 4) * 4;
+  // one tile per workgroup: 2 stages + bias row, strips inside the stages; persistent: strips behind stage 0, 2 bias rows
+  constexpr int SMEM = EARLY ? (STAGE + STRIPS > 2 * STAGE ? STAGE + STRIPS : 2 * STAGE) + 2 * BN * 4 : 2 * STAGE + BN * 4;
+  static_assert(2 * STAGE >= STRIPS && SMEM <= 160 * 1024, "LDS map of nt2_tile");
   p.tiles_m = (p.M + V2_BM - 1) / V2_BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   static unsigned long long attr_done = 0;  // one bit per device
@@ -662,7 +728,9 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
 
 template <int GM>
 int launch_v2_geglu(GemmNT2Params p, hipStream_t stream) {
-  constexpr int BN = 320, SMEM = 2 * (256 * 64 * 2 + BN * 64 * 2) + BN * 4;
+  constexpr int BN = 320, STAGE = 256 * 64 * 2 + BN * 64 * 2, STRIPS = 4 * 16 * (BN + 4) * 4;
+  constexpr int SMEM = (STAGE + STRIPS > 2 * STAGE ? STAGE + STRIPS : 2 * STAGE) + 2 * BN * 4;  // persistent LDS map of nt2_tile
+  static_assert(SMEM <= 160 * 1024, "LDS");
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = GM == 1 ? (p.inner + BN / 2 - 1) / (BN / 2) : (p.inner + BN - 1) / BN;
   p.splits = 1;
@@ -678,8 +746,10 @@ int launch_v2_geglu(GemmNT2Params p, hipStream_t stream) {
 template <int MT, int NT, int WM, int WN, int BK>
 int launch_v2(const GemmNT2Params& p, int splits, float* ws, hipStream_t stream) {
   if (p.mode == 3) return launch_v2_mode<MT, NT, WM, WN, BK, true, false>(p, splits, ws, stream);
+  if ((long)p.N * p.K * 2 >= (1L << 32)) return DA_ERR_SHAPE;  // 32-bit byte offsets into W
   if constexpr (WM * WN == 16) {  // early issue only where it was measured: the 16-wave form on 1x1 shapes
-    if (p.ksize == 1) return launch_v2_mode<MT, NT, WM, WN, BK, false, true>(p, splits, ws, stream);
+    // (its A rows are addressed by 32-bit byte offsets from the base: larger activations take the generic form)
+    if (p.ksize == 1 && (long)p.M * p.lda * 2 < (1L << 32)) return launch_v2_mode<MT, NT, WM, WN, BK, false, true>(p, splits, ws, stream);
   }
   return launch_v2_mode<MT, NT, WM, WN, BK, false, false>(p, splits, ws, stream);
 }
@@ -718,6 +788,7 @@ extern "C" int da_gemm_nt_geglu(const void* A, long lda, const void* W, void* F,
   DA_CLEAR_ERR();
   if (M <= 0 || inner <= 0 || K <= 0) return DA_ERR_SHAPE;
   if ((inner % 160) || (K % 64) || (lda & 7) || (ldf & 7) || (ldg & 7)) return DA_ERR_SHAPE;
+  if ((long)M * lda * 2 >= (1L << 32) || (long)inner * K * 4 >= (1L << 32)) return DA_ERR_SHAPE;  // 32-bit byte offsets of the DMA sources
   GemmNT2Params p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = F; p.bias = bias;
   p.rowbias = nullptr; p.R = nullptr;
@@ -737,6 +808,7 @@ extern "C" int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, c
   DA_CLEAR_ERR();
   if (M <= 0 || inner <= 0 || K <= 0) return DA_ERR_SHAPE;
   if ((inner % 320) || (K % 64) || (lddy & 7) || (ldf & 7) || (lddf & 7)) return DA_ERR_SHAPE;
+  if ((long)M * lddy * 2 >= (1L << 32) || (long)inner * K * 2 >= (1L << 32)) return DA_ERR_SHAPE;  // 32-bit byte offsets of the DMA sources
   GemmNT2Params p;
   p.A = (const bf16*)dY; p.W = (const bf16*)Wt; p.C = dF; p.bias = nullptr;
   p.rowbias = nullptr; p.R = nullptr;

@@ -1,6 +1,6 @@
 """Per-phase timeline of the implicit-GEMM tile (gemm_nt_v2.hip built with -DDA_STAMPS: `make -C diffusion_amd/csrc stamps`).
-Wave 0 of every workgroup writes s_memtime at: 0 tile start, 1 descriptors done, 2 stage 0 landed, 3 K loop done,
-4..7 epilogue strips done, 12 tile done (stores issued), 13 stores drained (vmcnt(0), diagnostic wait).
+Wave 0 of every workgroup writes s_memtime at: 0 kernel start, 1 before the wait for stage 0, 2 stage 0 landed, 3 K loop
+done, 8 next tile described and requested (persistent forms), 4..7 epilogue strips done, 12 tile done.
 Prints the median / p90 length of each phase over all tiles, in clock ticks and microseconds (ticks calibrated against
 the HIP-event duration of the launch: first stamp -> last stamp).
 usage: nt2_stamps.py [B=256] [shape ...]    shape = lin320 | ff_out320 | geglu320 | geglu_bwd320 | qkv320 | lin640 | conv320"""
@@ -51,8 +51,8 @@ def case(name):
     raise SystemExit(f'unknown shape {name}')
 
 
-PH = [('descr', 0, 1), ('stage0', 1, 2), ('kloop', 2, 3), ('strip0', 3, 4), ('strip1', 4, 5), ('strip2', 5, 6), ('strip3', 6, 7),
-      ('tile', 0, 12), ('drain', 12, 13)]
+PH = [('descr', 0, 1), ('wait0', 1, 2), ('kloop', 2, 3), ('next', 3, 8), ('strip0', 8, 4), ('strip0', 3, 4), ('strip1', 4, 5), ('strip2', 5, 6),
+      ('strip3', 6, 7), ('tile', 1, 12), ('tile', 0, 7)]
 for name in names:
     fn, fl = case(name)
     lib.da_debug_set_stamps(None)
@@ -70,17 +70,13 @@ for name in names:
     us = s.elapsed_time(e) * 1e3
     lib.da_debug_set_stamps(None)
     st = stamps.cpu().numpy()
-    st = st[st[:, 0] != 0]
-    has12 = (st[:, 12] != 0).all()
+    st = st[st[:, 3] != 0]
     tick_us = 1.0 / 2000.0   # the counters of the 8 XCDs are not synchronised: only differences within a tile mean anything
     print(f'== {name} B={B}: {len(st)} tiles, launch {us:.1f} us with stamps ({base_us:.1f} us without, {fl/base_us/1e6:.0f} TF/s); '
           f'us at a nominal 2.0 GHz shader clock')
     for ph, a, b in PH:
-        if (b in (12, 13) and not has12) or (st[:, b] == 0).any() or (st[:, a] == 0).any():
+        ok = (st[:, b] != 0) & (st[:, a] != 0)
+        if ok.sum() < len(st) // 2:
             continue
-        d = (st[:, b] - st[:, a]).astype(np.float64)
+        d = (st[ok, b] - st[ok, a]).astype(np.float64)
         print(f'   {ph:7s} median {np.median(d):8.0f} ticks {np.median(d)*tick_us:6.2f} us   p10 {np.percentile(d,10)*tick_us:6.2f}  p90 {np.percentile(d,90)*tick_us:6.2f}')
-    if not has12:   # one tile per workgroup: no stamp 12; the tile ends with the last strip
-        last = max(i for i in range(4, 12) if (st[:, i] != 0).all())
-        d = (st[:, last] - st[:, 0]).astype(np.float64)
-        print(f'   tile    median {np.median(d):8.0f} ticks {np.median(d)*tick_us:6.2f} us   p10 {np.percentile(d,10)*tick_us:6.2f}  p90 {np.percentile(d,90)*tick_us:6.2f}')
