@@ -251,6 +251,8 @@ extern int g_tn_variant;  // gemm_tn.hip
 extern int g_nt_korder;  // gemm_nt_v2.hip
 extern int g_nt_persist;
 static int g_nt_variant = 0;
+static int g_nt_mfma32 = 0;   // da_set_option("gemm_nt_mfma32", 0 never | -1 for K <= 320 | 1 always): the 256x320 form on
+                              // v_mfma_f32_32x32x16_bf16 (variant 15) where the cost model picks variant 12
 static int g_nt_splitk = 1;  // da_set_option("gemm_nt_splitk", 0/1)  // 0 auto, 1 force v1 (128x128), 4 / 5 force v2 with BN 128 / 160 (when eligible)
 
 // 1 -> gemm_nt_kernel (128x128), 4 / 5 / 10 / 12 -> gemm_nt2_kernel with BN 128 / 160 / 320 / 320.  12 is the default
@@ -294,7 +296,9 @@ static int pick_nt_variant_legacy(int M, int N, int K, int Cin, long ws_floats, 
 static int pick_nt_variant(int M, int N, int K, int Cin, long ws_floats, int* splits) {
   *splits = 1;
   if (Cin % 64 != 0) return 1;
-  if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10 || g_nt_variant == 11 || g_nt_variant == 12 || g_nt_variant == 14) return g_nt_variant;
+  if (g_nt_variant == 4 || g_nt_variant == 5 || g_nt_variant == 10 || g_nt_variant == 11 || g_nt_variant == 12 || g_nt_variant == 14 ||
+      g_nt_variant == 15 || g_nt_variant == 16)
+    return g_nt_variant;
   if (g_nt_variant != 0) return 1;
   if (!g_nt_dispatch) return pick_nt_variant_legacy(M, N, K, Cin, ws_floats, splits);
   struct Form { int variant, bn; double step_us, fixed_us; };
@@ -319,6 +323,10 @@ static int pick_nt_variant(int M, int N, int K, int Cin, long ws_floats, int* sp
     }
   }
   *splits = best_s;
+  // same tile on 32x32x16 matrix instructions (waves as 8 x 2): 10-15 % slower on long K (a third more LDS fragment reads);
+  // 7-12 % faster on the 5-step K = 320 linears in isolation (instruction issue paces the short loop), no difference inside
+  // the training step (540 vs 548 TFLOP/s on the 100 such launches) - kept as an option, off by default
+  if (best_v == 12 && (g_nt_mfma32 == 1 || (g_nt_mfma32 < 0 && K <= 320))) return 15;
   return best_v;
 }
 
@@ -346,6 +354,10 @@ extern "C" int da_set_option(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_nt_korder")) {
     g_nt_korder = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_mfma32")) {
+    g_nt_mfma32 = value;
     return DA_OK;
   }
   if (key && !strcmp(key, "gemm_tn_variant")) {

@@ -98,12 +98,19 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
 // EARLY: request the next stage at the START of the K-step instead of between its two MFMA halves.  Measured on the
 // 16-wave form: +3-4 % on 1x1 / linear shapes (A streamed from HBM, longer lead), -2-4 % on 3x3 convs (L2-resident taps;
 // the issue block delays the first MFMAs), so it is chosen by kernel size.
-template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU, bool EARLY>
+// MF: MFMA shape.  16 = v_mfma_f32_16x16x32_bf16 (MT x NT tiles of 16 x 16 per wave); 32 = v_mfma_f32_32x32x16_bf16 (tiles of
+// 32 x 32): the same FLOPs in half as many matrix instructions, each of which holds the SIMD's vector issue port for 8
+// cycles whatever its shape (MI355X_MICROARCH.md, cycle constants) - with four waves per SIMD also issuing 18-24
+// ds_read_b128 and the LDS-DMA pieces of the next stage every K-step, the 16x16x32 form spends 1,280 of a step's 2,560
+// matrix-pipe cycles on MFMA issue alone and the step measures ~3,500.
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU, bool EARLY, int MF = 16>
 DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   constexpr int NW = WM * WN;
-  constexpr int V2_BM = 16 * MT * WM, V2_BK = BK;
+  constexpr int V2_BM = MF * MT * WM, V2_BK = BK;
   static_assert((NW == 16 || NW == 8 || NW == 4) && (BK == 64 || BK == 32), "wave grid");
-  constexpr int BN = 16 * NT * WN;
+  static_assert(MF == 16 || (MF == 32 && GEGLU == 0 && BK == 64), "MFMA shape");
+  constexpr int BN = MF * NT * WN;
+  constexpr int SR = MF == 16 ? 16 : 8;  // rows per epilogue strip: the rows one accumulator register quad covers per wave
   constexpr int RG = 512 / BK;                // tile rows per 1-KiB DMA group (8 | 16)
   constexpr int LR = BK / 8;                  // lanes (16-B chunks) per row
   constexpr int AJ = V2_BM / RG / NW;         // A row groups per wave
@@ -119,7 +126,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   // requested right after the K loop, so that load (2.2-2.8 us of a 27 us tile by the clock stamps, plus ~0.9 us of
   // descriptor arithmetic waiting on nothing) is in flight under the epilogue instead of in front of the next K loop.
   constexpr int EPI_LD = BN + 4;
-  constexpr int STRIP = 16 * EPI_LD;  // floats per 16-row strip
+  constexpr int STRIP = SR * EPI_LD;  // floats per strip
   constexpr int STRIP_OFF = EARLY ? STAGE : 0;
   constexpr int BIAS_OFF = !EARLY ? 2 * STAGE : (STAGE + WM * STRIP * 4 > 2 * STAGE ? STAGE + WM * STRIP * 4 : 2 * STAGE);
   int vblock = vblock0;
@@ -134,7 +141,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   // the row block, so every SIMD gets the same share.
   auto task_of = [&](int ln, int pss, int tasks) {
     const bool ragged_last = (tasks % (64 * WN)) != 0 && pss == (tasks + 64 * WN - 1) / (64 * WN) - 1;
-    const int slot = ragged_last ? (wn + WN - wm % WN) % WN : wn;
+    const int slot = ragged_last ? (wn + WN - (wm * WN / 4) % WN) % WN : wn;  // SIMD of a wave = (wm * WN + wn) % 4
     return slot * 64 + ln + 64 * WN * pss;
   };
   // Per-lane values derived from the lane id inside the tile loop of the persistent forms would be hoisted out of it and
@@ -305,7 +312,8 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
     }
   };
 
-  f32x4 acc[MT][NT];
+  typedef float accv_t __attribute__((ext_vector_type(MF == 16 ? 4 : 16)));
+  accv_t acc[MT][NT];
 
   auto compute_half = [&](int stage, int s) {
     const char* Ab = smem + stage * STAGE;
@@ -318,18 +326,38 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
     // after the K-order change, and of every form once the body sits in the persistent loop).
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    const int chunk = s * 4 + (ln >> 4);
+    if constexpr (MF == 16) {
+      const int chunk = s * 4 + (ln >> 4);
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-      a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2<BK>(wm * (16 * MT) + i * 16 + (ln & 15), chunk));
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-      b[j] = *reinterpret_cast<const bf16x8*>(Bb + swz2<BK>(wn * (16 * NT) + j * 16 + (ln & 15), chunk));
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2<BK>(wm * (16 * MT) + i * 16 + (ln & 15), chunk));
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        b[j] = *reinterpret_cast<const bf16x8*>(Bb + swz2<BK>(wn * (16 * NT) + j * 16 + (ln & 15), chunk));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    } else {
+      // two 16-deep slices per half-step; lane = (row % 32, k-half): the 16 rows a ds_read_b128 lane group touches are 8
+      // even + 8 odd ones with 8 distinct (row >> 1) & 7 keys, so the 64-B-step swizzle stays conflict-free
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int chunk = s * 4 + ks * 2 + (ln >> 5);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          a[i] = *reinterpret_cast<const bf16x8*>(Ab + swz2<BK>(wm * (32 * MT) + i * 32 + (ln & 31), chunk));
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          b[j] = *reinterpret_cast<const bf16x8*>(Bb + swz2<BK>(wn * (32 * NT) + j * 32 + (ln & 31), chunk));
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
   };
 
   // stage 0 of the described tile has been requested; returns with the tile's products in acc and both stages idle
@@ -342,12 +370,14 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   __syncthreads();
   STAMP(2);
   {
-    const float* brow = reinterpret_cast<const float*>(smem + BIAS_OFF + bbuf * (BN * 4)) + wn * (16 * NT) + (fresh_lane() & 15);
+    const float* brow = reinterpret_cast<const float*>(smem + BIAS_OFF + bbuf * (BN * 4)) + wn * (MF * NT) + (fresh_lane() & (MF - 1));
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const float b = fold_bias ? brow[j * 16] : 0.f;
+      const float b = fold_bias ? brow[j * MF] : 0.f;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i][j] = f32x4{b, b, b, b};
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < (MF == 16 ? 4 : 16); ++e) acc[i][j][e] = b;
     }
   }
   for (int t = 0; t < nk; ++t) {
@@ -484,7 +514,8 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   // residual in 16*NT*2-byte pieces (160 B, straddling 128-B lines), which measured ~2.4 TB/s on the K=320 linears
   constexpr bool EPI_DB = !EARLY && 2 * WM * STRIP * 4 <= 2 * STAGE;  // double-buffered strips: one barrier per strip
   constexpr int CH = BN / 8;                              // 8-column chunks per row
-  constexpr int TASKS = 16 * CH;                          // (row, chunk) pairs per strip, shared by 64*WN lanes
+  constexpr int TASKS = SR * CH;                          // (row, chunk) pairs per strip, shared by 64*WN lanes
+  constexpr int NSI = MT * (MF == 16 ? 1 : 4);            // strips per wave: one per 16-row tile | per register quad of a 32-row tile
   constexpr int PASSES = (TASKS + 64 * WN - 1) / (64 * WN);
   // residual rows are fetched ahead of their strip (the MFMA operand registers are dead by now): with a load -> wait ->
   // store chain per strip the epilogue exposed one HBM latency per strip, ~37 us per 256x320 tile on the K=320 linears.
@@ -495,7 +526,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   // compiler's s_waitcnt conservative: with the validity branches around every load it cannot count the requests issued
   // since, waits vmcnt(0) before each use, and the strips got 20 % slower.
   constexpr int RBUD = NW == 16 ? 3 : 10;  // 16-byte registers for the ring
-  constexpr int RD = (MT < RBUD / PASSES) ? MT : (RBUD / PASSES < 1 ? 1 : RBUD / PASSES);
+  constexpr int RD = (NSI < RBUD / PASSES) ? NSI : (RBUD / PASSES < 1 ? 1 : RBUD / PASSES);
   int trow[PASSES], tcol[PASSES];
   bool tval[PASSES];
 #pragma unroll
@@ -505,13 +536,13 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
     tcol[pss] = (task - trow[pss] * CH) * 8;
     tval[pss] = task < TASKS && n0e + tcol[pss] < p.N;
   }
-  const int mrow0 = m0e + wm * (16 * MT);
+  const int mrow0 = m0e + wm * (MF * MT);
   const bool has_r = p.R != nullptr && p.splits == 1;
   bf16x8 rres[RD][PASSES];
   auto fetch_r = [&](int i, int slot) {
 #pragma unroll
     for (int pss = 0; pss < PASSES; ++pss) {
-      const int m = mrow0 + i * 16 + trow[pss];
+      const int m = mrow0 + i * SR + trow[pss];
       if (tval[pss] && m < p.M) rres[slot][pss] = ld8(p.R + (long)m * p.ldr + n0e + tcol[pss]);
     }
   };
@@ -522,18 +553,20 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
     if (has_r) fetch_r(i, i);
   }
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+  for (int i = 0; i < NSI; ++i) {  // strip i = rows [i * SR, i * SR + SR) of the wave's row block
     float* ew = strips + ((EPI_DB ? (i & 1) * WM : 0) + wm) * STRIP;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        ew[((el >> 4) * 4 + e) * EPI_LD + wn * (16 * NT) + j * 16 + (el & 15)] = acc[i][j][e];
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (MF == 16) ew[((el >> 4) * 4 + e) * EPI_LD + wn * (16 * NT) + j * 16 + (el & 15)] = acc[i][j][e];
+        else ew[((el >> 5) * 4 + e) * EPI_LD + wn * (32 * NT) + j * 32 + (el & 31)] = acc[i / 4][j][(i & 3) * 4 + e];
+      }
     lds_barrier();
 #pragma unroll
     for (int pss = 0; pss < PASSES; ++pss) {
       const int row = trow[pss], col8 = tcol[pss];
-      const int m = mrow0 + i * 16 + row;
+      const int m = mrow0 + i * SR + row;
       const int n = n0e + col8;
       if (tval[pss] && m < p.M) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ew[row * EPI_LD + col8]);
@@ -583,7 +616,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
         }
       }
     }
-    if (has_r && i + RD < MT) fetch_r(i + RD, i % RD);
+    if (has_r && i + RD < NSI) fetch_r(i + RD, i % RD);
     if (!EPI_DB) lds_barrier();  // single strip buffer: everyone is done reading before it is rewritten
     STAMP(4 + i);
   }
@@ -623,10 +656,10 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
 // list with stride gridDim.x inside nt2_tile, requesting the next tile's first K-step before the epilogue of the current
 // one, so neither that load nor the epilogue's stores are waited for between tiles, and no workgroup is torn down and
 // re-dispatched per tile.
-template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU = 0, bool EARLY = false>
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU = 0, bool EARLY = false, int MF = 16>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt2_kernel(GemmNT2Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY>(p, blockIdx.x, smem);
+  nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY, MF>(p, blockIdx.x, smem);
 }
 
 // split-K finalize: out[m][n] = alpha * sum_s slab[s][m][n] + bias[n] + rowbias[image(m)][n] + R[m][n]
@@ -688,19 +721,19 @@ static int persistent_grid(int total_blocks) {
   return total_blocks < n ? total_blocks : n;
 }
 
-template <int MT, int NT, int WM, int WN, int BK, bool UPS, bool EARLY>
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, bool EARLY, int MF = 16>
 int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream) {
   GemmNT2Params p = p0;
-  constexpr int V2_BM = 16 * MT * WM, V2_BK = BK, NTHREADS = 64 * WM * WN;
-  constexpr int BN = 16 * NT * WN;
-  constexpr int STAGE = V2_BM * V2_BK * 2 + BN * V2_BK * 2, STRIPS = WM * 16 * (BN + 4) * 4;
+  constexpr int V2_BM = MF * MT * WM, V2_BK = BK, NTHREADS = 64 * WM * WN;
+  constexpr int BN = MF * NT * WN;
+  constexpr int STAGE = V2_BM * V2_BK * 2 + BN * V2_BK * 2, STRIPS = WM * (MF == 16 ? 16 : 8) * (BN + 4) * 4;
   // one tile per workgroup: 2 stages + bias row, strips inside the stages; persistent: strips behind stage 0, 2 bias rows
   constexpr int SMEM = EARLY ? (STAGE + STRIPS > 2 * STAGE ? STAGE + STRIPS : 2 * STAGE) + 2 * BN * 4 : 2 * STAGE + BN * 4;
   static_assert(2 * STAGE >= STRIPS && SMEM <= 160 * 1024, "LDS map of nt2_tile");
   p.tiles_m = (p.M + V2_BM - 1) / V2_BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   static unsigned long long attr_done = 0;  // one bit per device
-  if (da_ensure_dyn_smem((const void*)gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
+  if (da_ensure_dyn_smem((const void*)gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
   const int nk_total = p.K / V2_BK;
   p.splits = splits > 1 ? splits : 1;
   p.ksteps_per_split = (nk_total + p.splits - 1) / p.splits;
@@ -711,7 +744,7 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
   if (p.splits > 1) {
     GemmNT2Params pk = p;
     pk.C = ws;  // partial slabs
-    hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY>), dim3(grid), dim3(NTHREADS), SMEM,
+    hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF>), dim3(grid), dim3(NTHREADS), SMEM,
                        stream, pk);
     DA_CHECK_LAUNCH();
     const long total = (long)p.M * (p.N >> 3);
@@ -721,7 +754,7 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
     DA_CHECK_LAUNCH();
     return DA_OK;
   }
-  hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY>), dim3(grid), dim3(NTHREADS), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF>), dim3(grid), dim3(NTHREADS), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -743,15 +776,15 @@ int launch_v2_geglu(GemmNT2Params p, hipStream_t stream) {
   return DA_OK;
 }
 
-template <int MT, int NT, int WM, int WN, int BK>
+template <int MT, int NT, int WM, int WN, int BK, int MF = 16>
 int launch_v2(const GemmNT2Params& p, int splits, float* ws, hipStream_t stream) {
-  if (p.mode == 3) return launch_v2_mode<MT, NT, WM, WN, BK, true, false>(p, splits, ws, stream);
+  if (p.mode == 3) return launch_v2_mode<MT, NT, WM, WN, BK, true, false, MF>(p, splits, ws, stream);
   if ((long)p.N * p.K * 2 >= (1L << 32)) return DA_ERR_SHAPE;  // 32-bit byte offsets into W
   if constexpr (WM * WN == 16) {  // early issue only where it was measured: the 16-wave form on 1x1 shapes
     // (its A rows are addressed by 32-bit byte offsets from the base: larger activations take the generic form)
-    if (p.ksize == 1 && (long)p.M * p.lda * 2 < (1L << 32)) return launch_v2_mode<MT, NT, WM, WN, BK, false, true>(p, splits, ws, stream);
+    if (p.ksize == 1 && (long)p.M * p.lda * 2 < (1L << 32)) return launch_v2_mode<MT, NT, WM, WN, BK, false, true, MF>(p, splits, ws, stream);
   }
-  return launch_v2_mode<MT, NT, WM, WN, BK, false, false>(p, splits, ws, stream);
+  return launch_v2_mode<MT, NT, WM, WN, BK, false, false, MF>(p, splits, ws, stream);
 }
 
 }  // namespace
@@ -778,6 +811,8 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
   if (variant == 10) return launch_v2<8, 5, 2, 4, 64>(p, splits, ws, stream);
   if (variant == 11) return launch_v2<4, 10, 2, 2, 32>(p, 1, ws, stream);  // 128 x 320 x 32, 4 waves, 2 workgroups / CU
   if (variant == 12) return launch_v2<4, 5, 4, 4, 64>(p, splits, ws, stream);  // 256 x 320 x 64, 16 waves (4 / SIMD)
+  if (variant == 15) return launch_v2<1, 5, 8, 2, 64, 32>(p, splits, ws, stream);     // 256 x 320 x 64, 16 waves as 8 x 2, 32x32x16 MFMA
+  if (variant == 16) return launch_v2<2, 5, 4, 2, 64, 32>(p, splits, ws, stream);     // 256 x 320 x 64, 8 waves as 4 x 2 (64 x 160 each), 32x32x16 MFMA
   if (variant == 14) return launch_v2<4, 4, 4, 4, 64>(p, splits, ws, stream);      // 256 x 256 x 64, 16 waves: N = 256 / 512 (VAE encoder)
   return variant == 5 ? launch_v2<4, 5, 4, 2, 64>(p, splits, ws, stream) : launch_v2<4, 4, 4, 2, 64>(p, splits, ws, stream);
 }

@@ -168,7 +168,7 @@ def test_gemm_nt_geglu_bwd_fused(ops, dev):
     check(got[:, inner:], g.grad, what='fused geglu bwd d(gate)')
 
 
-@pytest.mark.parametrize('variant', [4, 5, 10, 11, 12, 14])
+@pytest.mark.parametrize('variant', [4, 5, 10, 11, 12, 14, 15, 16])
 def test_gemm_nt_v2_variants(ops, dev, variant):
     """The 256x(128|160) LDS-DMA kernel forced on: linear + every conv mode, ragged M / N tails, fused epilogue."""
     ops.set_option('gemm_nt_variant', variant)
