@@ -248,7 +248,6 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
                            hipStream_t stream);
 
 extern int g_tn_variant;  // gemm_tn.hip
-extern int g_tn_issue;    // gemm_tn_v2.hip
 extern int g_nt_korder;  // gemm_nt_v2.hip
 extern int g_nt_persist;
 static int g_nt_variant = 0;
@@ -359,10 +358,6 @@ extern "C" int da_set_option(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_nt_mfma32")) {
     g_nt_mfma32 = value;
-    return DA_OK;
-  }
-  if (key && !strcmp(key, "gemm_tn_issue")) {
-    g_tn_issue = value;
     return DA_OK;
   }
   if (key && !strcmp(key, "gemm_tn_variant")) {

@@ -58,7 +58,7 @@ DEVINL void glds16_tn(const void* gsrc, char* lds_dst) {
 // arithmetic: dY loads are uniform base + a constant lane offset, X loads add one select on a precomputed validity
 // mask.  The generic path (strided / upsampled gathers, ragged M) recomputes coordinates each step: ~105 VALU
 // instructions per step that run on every wave with the matrix pipe idle.
-template <int T2_BK, bool FAST, int ISSUE = 0>
+template <int T2_BK, bool FAST>
 __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   constexpr int T2_SB = T2_BK * 2;
   constexpr int T2_B_BYTES = T2_MS * T2_SB;
@@ -349,9 +349,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     issue_fast(0, true);
     __syncthreads();
     for (int t = 0; t < nsteps; ++t) {  // one basic block: no branch around the issue
-      if constexpr (ISSUE == 0) issue_fast((t + 1) & 1, t + 1 < nsteps);
+      // Placement of the request, measured (tools/tn_ab.py, batch 256): here for every wave; between the halves -7..+2 % by
+      // shape; the two waves of a SIMD (w, w + 4) taking turns - one here, one between its halves, so that one's request
+      // block (~900-1300 cycles for its 8 pieces) would run under the other's MFMAs - -6..-14 %; turns by wave parity +-2 %.
+      issue_fast((t + 1) & 1, t + 1 < nsteps);
       compute_half(t & 1, 0);
-      if constexpr (ISSUE == 1) issue_fast((t + 1) & 1, t + 1 < nsteps);
       compute_half(t & 1, 1);
       __syncthreads();
     }
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(256) void tn_slab_reduce_kernel(GemmTN2Params p) {
   }
 }
 
-template <int BK, bool FAST, int ISSUE = 0>
+template <int BK, bool FAST>
 int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
   constexpr int SMEM = 2 * (T2_A_BYTES + T2_MS * BK * 2);
   p.tiles_n = (p.N + T2_BN - 1) / T2_BN;
@@ -463,10 +465,10 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
   p.splits = (p.M + mps - 1) / mps;
   p.m_per_split = mps;
   static unsigned long long attr_done = 0;  // one bit per device
-  if (da_ensure_dyn_smem((const void*)gemm_tn2_kernel<BK, FAST, ISSUE>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
+  if (da_ensure_dyn_smem((const void*)gemm_tn2_kernel<BK, FAST>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
   p.slab = nullptr;
   if (p.splits > 1 && ws && (long)tiles * p.splits * T2_BN * BK <= ws_floats && (p.Kt & 3) == 0) p.slab = ws;
-  hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST, ISSUE>), dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST>), dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   if (p.slab) {
     const long total = (long)p.N * (p.Kt >> 2);
@@ -494,8 +496,6 @@ int da_gemm_tn_v2_fast_period(int M, int N, int Hin, int Win, int Hout, int Wout
   return 0;
 }
 
-int g_tn_issue = 0;  // da_set_option("gemm_tn_issue", 0 | 1): FAST path requests the next stage at the step's start | between its halves
-
 // Called by da_gemm_tn_wgrad (gemm_tn.hip) after argument validation.
 int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias,
                            int M, int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, float* ws,
@@ -512,6 +512,5 @@ int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X
   p.slab = nullptr;
   (void)variant;  // the 320x256 instantiation (160 accumulators) spills on gfx950 and lost to 320x192 everywhere
   p.period = da_gemm_tn_v2_fast_period(M, N, Hin, Win, Hout, Wout, mode);
-  if (p.period && g_tn_issue == 1) return launch_tn2<192, true, 1>(p, ws, ws_floats, stream);
   return p.period ? launch_tn2<192, true>(p, ws, ws_floats, stream) : launch_tn2<192, false>(p, ws, ws_floats, stream);
 }

@@ -67,9 +67,7 @@ int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* 
  *   "gemm_nt_splitk"    1 (default) split-K allowed | 0 never split
  *   "gemm_nt_persist"   -1 (default) linears / fused GEGLU run as one resident workgroup per CU walking the tile list |
  *                       n > 0 that many resident workgroups | 0 one workgroup per tile
- *   "gemm_tn_variant"   0 auto | 1 the 128x128x32 wgrad kernel | 2 the 320x192x64 LDS-DMA wgrad kernel
- *   "gemm_tn_issue"     0 (default) the wgrad kernel requests the next stage at the start of a step | 1 between its two halves
- *                       (measured -7 .. +2 % by shape) */
+ *   "gemm_tn_variant"   0 auto | 1 the 128x128x32 wgrad kernel | 2 the 320x192x64 LDS-DMA wgrad kernel */
 int da_set_option(const char* key, int value);
 /* which kernel da_gemm_nt dispatches to for (M, N, K, Cin) given a split-K workspace of that many floats: 1 = gemm_nt_kernel (128x128 tile), 4 / 5 / 10 =
  * gemm_nt2_kernel with a 256x128 / 256x160 / 256x320 tile, 12 = the 16-wave 256x320 form, 14 = the 16-wave 256x256 form,
