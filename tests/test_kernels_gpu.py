@@ -168,6 +168,43 @@ def test_gemm_nt_geglu_bwd_fused(ops, dev):
     check(got[:, inner:], g.grad, what='fused geglu bwd d(gate)')
 
 
+@pytest.mark.parametrize('grid', [0, 1, 3, 7])
+def test_gemm_nt_persistent_tile_walk(ops, dev, grid):
+    """Linears and the fused GEGLU forms walk the tile list with a fixed grid of resident workgroups and request the next
+    tile's first K-step before the current tile's epilogue (bias rows double-buffered in LDS).  gemm_nt_persist = n makes
+    every workgroup walk many tiles (n = 1: all of them, in order), 0 = one tile per workgroup; all must agree bit for bit."""
+    M, N, K = 1500, 968, 320    # 6 x 4 tiles, ragged in both directions
+    A = rnd(M, K, dev=dev, seed=1).to(BF); W = rnd(N, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
+    bias = rnd(N, dev=dev, seed=3); R = rnd(M, N, dev=dev, seed=4).to(BF)
+    inner = 640
+    Wg = rnd(2 * inner, K, dev=dev, seed=5, scale=K**-0.5).to(BF); bg = rnd(2 * inner, dev=dev, seed=6)
+    dy = rnd(M, K, dev=dev, seed=7).to(BF); wt = rnd(inner, K, dev=dev, seed=8, scale=inner**-0.5).to(BF)
+
+    def run():
+        out = torch.empty(M, N, device=dev, dtype=BF)
+        ops.gemm_nt(A, W, out, ops.Geom.linear(M), bias=bias, residual=R)
+        f = torch.empty(M, 2 * inner, device=dev, dtype=BF); g = torch.empty(M, inner, device=dev, dtype=BF)
+        ops.gemm_nt_geglu(A, Wg, f, g, bg)
+        df = torch.empty(M, 2 * inner, device=dev, dtype=BF)
+        ops.gemm_nt_geglu_bwd(dy, wt, f, df)
+        return out, f, g, df
+
+    ops.set_option('gemm_nt_variant', 12)
+    try:
+        ops.set_option('gemm_nt_persist', -1)
+        ref = run()
+        ops.set_option('gemm_nt_persist', grid)
+        got = run()
+    finally:
+        ops.set_option('gemm_nt_persist', -1)
+        ops.set_option('gemm_nt_variant', 0)
+    for r, g_ in zip(ref, got):
+        assert torch.equal(r, g_)
+    check(ref[0], A.float() @ W.float().t() + bias + R.float(), what='persistent linear')
+    h = A.float() @ Wg.float().t() + bg
+    check(ref[2], h[:, :inner] * F.gelu(h[:, inner:]), what='persistent geglu')
+
+
 @pytest.mark.parametrize('variant', [4, 5, 10, 11, 12, 14, 15, 16])
 def test_gemm_nt_v2_variants(ops, dev, variant):
     """The 256x(128|160) LDS-DMA kernel forced on: linear + every conv mode, ragged M / N tails, fused epilogue."""
