@@ -380,6 +380,19 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
         for (int e = 0; e < (MF == 16 ? 4 : 16); ++e) acc[i][j][e] = b;
     }
   }
+#ifdef DA_STAMPS
+  // K-loop phase sums of wave 0 (no memory traffic inside the loop): slots 8..11 = cycles from the step's start to the end
+  // of MFMA half 0 | of the request block | of MFMA half 1 (all "issued") | of the barrier
+  unsigned long long ph[4] = {0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime();
+#define KSTAMP(i)                                         \
+  do {                                                    \
+    const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
+    ph[i] += tn_ - tp;                                    \
+    tp = tn_;                                             \
+  } while (0)
+#else
+#define KSTAMP(i) do {} while (0)
+#endif
   for (int t = 0; t < nk; ++t) {
     // the address arithmetic + DMA issue of step t+1 sits BETWEEN the two MFMA halves of step t: every wave leaves
     // the barrier at the same time, so issuing first would idle the matrix pipe of all four SIMDs during it
@@ -389,14 +402,22 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
       compute_half(t & 1, 1);
     } else if constexpr (BK == 64) {
       compute_half(t & 1, 0);
+      KSTAMP(0);
       issue((t + 1) & 1, t + 1 < nk);
+      KSTAMP(1);
       compute_half(t & 1, 1);
+      KSTAMP(2);
     } else {  // one 32-deep MFMA pass per step; the co-resident workgroup covers the issue slot
       issue((t + 1) & 1, t + 1 < nk);
       compute_half(t & 1, 0);
     }
     __syncthreads();  // vmcnt(0): step t+1 has landed; barrier: everyone is done reading stage t
+    KSTAMP(3);
   }
+#ifdef DA_STAMPS
+  if (threadIdx.x == 0 && g_stamp_buf)
+    for (int i = 0; i < 4; ++i) g_stamp_buf[(long)vblock * 16 + 8 + i] = ph[i];
+#endif
   STAMP(3);
   };  // kloop()
 

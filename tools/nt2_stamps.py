@@ -51,7 +51,7 @@ def case(name):
     raise SystemExit(f'unknown shape {name}')
 
 
-PH = [('descr', 0, 1), ('wait0', 1, 2), ('kloop', 2, 3), ('next', 3, 8), ('strip0', 8, 4), ('strip0', 3, 4), ('strip1', 4, 5), ('strip2', 5, 6),
+PH = [('descr', 0, 1), ('wait0', 1, 2), ('kloop', 2, 3), ('strip0', 3, 4), ('strip0', 3, 4), ('strip1', 4, 5), ('strip2', 5, 6),
       ('strip3', 6, 7), ('tile', 1, 12), ('tile', 0, 7)]
 for name in names:
     fn, fl = case(name)
@@ -74,6 +74,12 @@ for name in names:
     tick_us = 1.0 / 2000.0   # the counters of the 8 XCDs are not synchronised: only differences within a tile mean anything
     print(f'== {name} B={B}: {len(st)} tiles, launch {us:.1f} us with stamps ({base_us:.1f} us without, {fl/base_us/1e6:.0f} TF/s); '
           f'us at a nominal 2.0 GHz shader clock')
+    if name.startswith('conv'):   # per-K-step phase sums of wave 0 (slots 8..11), one tile per workgroup
+        k = st[:, 8:12].astype(np.float64)
+        nk = 9 * int(name[4:]) // 64
+        tot = k.sum(1)
+        print(f'   K loop: {np.median(tot)/nk:7.0f} ticks / step (ideal MFMA 2560) = half0 {np.median(k[:,0])/nk:6.0f} + requests {np.median(k[:,1])/nk:6.0f} '
+              f'+ half1 {np.median(k[:,2])/nk:6.0f} + barrier {np.median(k[:,3])/nk:6.0f}')
     for ph, a, b in PH:
         ok = (st[:, b] != 0) & (st[:, a] != 0)
         if ok.sum() < len(st) // 2:
