@@ -17,7 +17,14 @@ The exchange itself is selectable (constructor arguments or the environment):
                           every rank sends shard j straight to peer j, all 7 links busy at once
   payload     'fp32' (default) the gradient as it lies; 'bf16' a bf16 staging copy (half the bytes on the links; the
               SUM is then rounded to 8 significant bits per element - opt-in).
-  DA_DP_COLLECTIVE / DA_DP_PAYLOAD override the defaults.
+  overlap     True (default) buckets are exchanged on the side stream while backward still runs; False: all buckets
+              are exchanged after backward (``flush``).  Why one might want that: the GEMM kernels are launched as one
+              workgroup per CU (persistent tile walks of exactly #CUs workgroups, weight-gradient grids sized to one
+              round of the chip), and a workgroup of theirs needs a whole CU; every CU an RCCL channel occupies while
+              such a launch starts pushes workgroups into a second round, so kernels that overlap a collective can
+              take up to twice as long.  Unmeasured - no multi-GPU node was available to this build; the switch is
+              here so that the first scaling run can decide.
+  DA_DP_COLLECTIVE / DA_DP_PAYLOAD / DA_DP_OVERLAP (0 | 1) override the defaults.
 """
 from __future__ import annotations
 
@@ -30,7 +37,7 @@ import torch.distributed as dist
 class BucketedAllReducer:
 
     def __init__(self, flat_grad: torch.Tensor, bucket_elems: int = 64 * 1024 * 1024, group=None, align: int = 64,
-                 collective: Optional[str] = None, payload: Optional[str] = None):
+                 collective: Optional[str] = None, payload: Optional[str] = None, overlap: Optional[bool] = None):
         if flat_grad.dim() != 1 or not flat_grad.is_contiguous():
             raise ValueError('flat_grad must be a contiguous 1-D tensor')
         self.flat = flat_grad
@@ -51,6 +58,7 @@ class BucketedAllReducer:
         self.payload = payload or os.environ.get('DA_DP_PAYLOAD', 'fp32')
         if self.collective not in ('allreduce', 'rs_ag') or self.payload not in ('fp32', 'bf16'):
             raise ValueError(f'collective must be allreduce|rs_ag and payload fp32|bf16, got {self.collective}, {self.payload}')
+        self.overlap = (os.environ.get('DA_DP_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
         self._stage = {}
 
     def _exchange(self, view: torch.Tensor):
@@ -111,12 +119,19 @@ class BucketedAllReducer:
     def ready(self, lo: int):
         """Every gradient at flat offsets >= lo is final."""
         lo = (lo // self.align) * self.align
+        if not self.overlap:
+            return            # everything goes out in flush(), bucket by bucket
         if self.hi - lo >= self.bucket:
             self._launch(lo, self.hi)
             self.hi = lo
 
     def flush(self):
         """Launch what is left ([0, hi)) and make the current stream wait for every bucket."""
+        if not self.overlap:      # same bucket boundaries as the overlapped schedule would have produced
+            while self.hi > self.bucket:
+                lo = ((self.hi - self.bucket) // self.align) * self.align
+                self._launch(lo, self.hi)
+                self.hi = lo
         self._launch(0, self.hi)
         self.hi = 0
         for h in self.handles:

@@ -13,14 +13,14 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, q, collective='allreduce', payload='fp32'):
+def _worker(rank, world, port, n, q, collective='allreduce', payload='fp32', overlap=True):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from diffusion_amd.parallel import BucketedAllReducer
     g = torch.Generator().manual_seed(100 + rank)
     flat = torch.randn(n, generator=g)
     mine = flat.clone()
-    red = BucketedAllReducer(flat, bucket_elems=1000, align=64, collective=collective, payload=payload)
+    red = BucketedAllReducer(flat, bucket_elems=1000, align=64, collective=collective, payload=payload, overlap=overlap)
     assert red.enabled and red.world_size == world
     red.begin()
     # gradients become final back-to-front, in uneven block sizes (like the U-Net's tape walk)
@@ -28,6 +28,7 @@ def _worker(rank, world, port, n, q, collective='allreduce', payload='fp32'):
     for step in (300, 900, 64, 2000, 10, 1500, 700):
         lo = max(0, lo - step)
         red.ready(lo)
+        assert overlap or not red.launched    # overlap off: nothing leaves before flush()
     red.flush()
     covered = torch.zeros(n, dtype=torch.int32)
     for a, b in red.launched:
@@ -62,6 +63,23 @@ def test_bucketed_allreduce_gloo_world2(collective, payload):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] >= 3  # several buckets were launched before the final flush
+
+
+def test_bucketed_allreduce_after_backward_gloo_world2():
+    """overlap=False (DA_DP_OVERLAP=0): every bucket is exchanged in flush(), same coverage and sums."""
+    world, n = 2, 6001
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, 'allreduce', 'fp32', False)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] >= 3
 
 
 def _loader_worker(rank, world, port, q):
