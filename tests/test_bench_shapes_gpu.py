@@ -255,3 +255,20 @@ def test_groupnorm_at_bench_shape(ops, dev, B, HW, C):
     var = xf.var(dim=(1, 3), unbiased=False, keepdim=True)
     n = ((xf - mean) * torch.rsqrt(var + eps)).reshape(B * HW, C) * gamma + beta
     check_blocks(y, F.silu(n), what='groupnorm+silu fwd')
+
+
+def test_linear_input_of_4_gib_takes_the_pointer_form(ops, dev):
+    """The persistent ksize-1 form addresses A rows by 32-bit byte offsets from the base; an activation of 4 GiB or more must
+    be routed to the 64-bit pointer form of the same tile (launch_v2's guard) - rows beyond the 4 GiB mark are checked."""
+    M, K, N = (1 << 21) + 192, 1024, 320          # A = 4.0 GiB + 384 KiB of bf16
+    A = torch.empty(M, K, device=dev, dtype=BF)
+    for lo in range(0, M, 1 << 18):               # filled in slices: no fp32 copy of the whole tensor
+        hi = min(M, lo + (1 << 18))
+        A[lo:hi] = rnd(hi - lo, K, dev=dev, seed=lo // (1 << 18)).to(BF)
+    W = rnd(N, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
+    bias = rnd(N, dev=dev, seed=3)
+    out = torch.empty(M, N, device=dev, dtype=BF)
+    ops.gemm_nt(A, W, out, ops.Geom.linear(M), bias=bias)
+    for lo in (0, (1 << 20) - 128, M - 512):      # first rows, rows straddling 2 GiB, the last rows (past 4 GiB)
+        ref = A[lo:lo + 512].float() @ W.float().t() + bias
+        check_blocks(out[lo:lo + 512], ref, what=f'rows {lo}..')
