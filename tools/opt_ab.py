@@ -4,6 +4,9 @@ usage: opt_ab.py <option> <valA> <valB> [B=256] [kinds=conv,lin] [key=val ...]  
 import sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from diffusion_amd import _lib
+if os.environ.get('DA_LIB_ALT'):   # an alternative build of the library next to the shipped one (compile-time experiments)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ['DA_LIB_ALT'])
 from diffusion_amd import ops
 from diffusion_amd.ops import Geom
 
