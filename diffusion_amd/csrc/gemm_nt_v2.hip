@@ -83,10 +83,9 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// MT x NT = 16x16 MFMA tiles per wave; WM x WN = wave grid; BM = 16*MT*WM, BN = 16*NT*WN; BK = K-step (64 | 32).
-// 8 waves x BK 64: one workgroup per CU (the long-K workhorse).  4 waves x BK 32: 56 KiB of LDS, two workgroups per CU,
-// so that with only a few K-steps per tile (1x1 convs / linears with K <= 640) one workgroup's prologue and store
-// epilogue overlap the other's MFMAs.
+// MT x NT = MFMA tiles (MF x MF, see MF below) per wave; WM x WN = wave grid; BM = MF*MT*WM, BN = MF*NT*WN; BK = K-step
+// (64 | 32).  The shipped workhorse is <4, 5, 4, 4>: 256 x 320 x 64, 16 waves (4 per SIMD, <= 128 VGPRs), one workgroup per
+// CU; the 8-wave forms serve small / odd shapes, the 4-wave BK-32 form (two workgroups per CU) is a test-only instantiation.
 // UPS: gather mode 3 (conv over a nearest-2x upsampled image) - a compile-time split so that the K loop of the other
 // modes stays one basic block.
 // GEGLU: the feed-forward input projection with its activation fused (diffusers GEGLU: out = value * gelu(gate)).  A
@@ -95,9 +94,11 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
 // pre-activation (kept for backward) and the gated output, which saves the separate pass that re-read the former.
 // GEGLU == 2 is the backward counterpart on the dgrad of the FF output projection: the tile of d(gated) never goes to
 // HBM; the epilogue reads the saved pre-activation, applies the GEGLU derivative and stores d(pre-activation).
-// EARLY: request the next stage at the START of the K-step instead of between its two MFMA halves.  Measured on the
-// 16-wave form: +3-4 % on 1x1 / linear shapes (A streamed from HBM, longer lead), -2-4 % on 3x3 convs (L2-resident taps;
-// the issue block delays the first MFMAs), so it is chosen by kernel size.
+// EARLY (ksize 1, mode 0 only: linears, 1x1 convs, the fused GEGLU forms): request the next stage at the START of the K-step
+// instead of between its two MFMA halves (measured on the 16-wave form: +3-4 % on these shapes - A streamed from HBM,
+// longer lead -, -2-4 % on 3x3 convs), address A rows by 32-bit byte offsets from a uniform base, and run as a
+// PERSISTENT grid: one resident workgroup per CU walks the tile list and requests the next tile's first K-step before the
+// current tile's epilogue (LDS map below).
 // MF: MFMA shape.  16 = v_mfma_f32_16x16x32_bf16 (MT x NT tiles of 16 x 16 per wave); 32 = v_mfma_f32_32x32x16_bf16 (tiles of
 // 32 x 32): the same FLOPs in half as many matrix instructions, each of which holds the SIMD's vector issue port for 8
 // cycles whatever its shape (MI355X_MICROARCH.md, cycle constants) - with four waves per SIMD also issuing 18-24
