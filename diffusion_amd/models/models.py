@@ -108,7 +108,7 @@ def stable_diffusion_2(
 
     if build_encoders is None:
         build_encoders = not precomputed_latents
-    vae = text_encoder = vae_hip = None
+    vae = text_encoder = vae_hip = text_hip = None
     from .text import build_text_encoder, build_tokenizer
     tokenizer = build_tokenizer(os.path.join(local, 'tokenizer') if local else None)
     if build_encoders:
@@ -132,7 +132,14 @@ def stable_diffusion_2(
             from .vae_hip import VAEEncoderHIP
             vae_hip = VAEEncoderHIP(vae.to('cuda'))
         vae = vae.to('cuda', dtype)
-        text_encoder = build_text_encoder(te_dir, dtype, hidden_size=unet_config.cross_attention_dim).to('cuda')
+        text_encoder = build_text_encoder(te_dir, torch.float32, hidden_size=unet_config.cross_attention_dim).to('cuda')
+        text_hip = None
+        if os.environ.get('DA_TEXT_HIP', '1') != '0' and text_encoder.config.hidden_size % 64 == 0 and \
+                text_encoder.config.hidden_size // text_encoder.config.num_attention_heads == 64:
+            # the frozen text encoder on the HIP kernels (models/text_hip.py), built from the fp32 weights
+            from .text_hip import TextEncoderHIP
+            text_hip = TextEncoderHIP(text_encoder)
+        text_encoder = text_encoder.to(dtype)
     noise_scheduler = DDPMScheduler(prediction_type=unet_config.prediction_type)
     inference_noise_scheduler = DDIMScheduler(prediction_type=unet_config.prediction_type)
 
@@ -153,4 +160,5 @@ def stable_diffusion_2(
         fsdp=fsdp,
     )
     model.vae_hip = vae_hip if build_encoders else None
+    model.text_hip = text_hip if build_encoders else None
     return model

@@ -129,6 +129,12 @@ class StableDiffusion(ComposerModel):
         self._pending = None
 
     # ------------------------------------------------------------------------------------------
+    def _text_states(self, input_ids):
+        """``text_encoder(ids)[0]`` (reference :168,172): the HIP-kernel walk of the frozen weights when the factory built
+        one (models/text_hip.py), else the PyTorch-ROCm module."""
+        enc = getattr(self, 'text_hip', None)
+        return (enc if enc is not None else self.text_encoder)(input_ids)[0]
+
     def _encode(self, batch):
         """latents / conditioning selection, reference :155-174."""
         if self.precomputed_latents and self.image_latents_key in batch and self.text_latents_key in batch:
@@ -144,14 +150,14 @@ class StableDiffusion(ComposerModel):
             if vae_hip is not None:
                 latents = vae_hip.encode(inputs)['latent_dist'].sample().data
                 with torch.autocast('cuda', enabled=False):
-                    conditioning = self.text_encoder(conditioning)[0]
+                    conditioning = self._text_states(conditioning)
             elif self.encode_latents_in_fp16:
                 with torch.autocast('cuda', enabled=False):
                     latents = self.vae.encode(inputs.half())['latent_dist'].sample().data
-                    conditioning = self.text_encoder(conditioning)[0]
+                    conditioning = self._text_states(conditioning)
             else:
                 latents = self.vae.encode(inputs)['latent_dist'].sample().data
-                conditioning = self.text_encoder(conditioning)[0]
+                conditioning = self._text_states(conditioning)
         latents *= 0.18215
         return latents, conditioning
 
@@ -327,7 +333,7 @@ class StableDiffusion(ComposerModel):
                 tokenized_prompts = self.tokenizer(prompt, padding='max_length',
                                                    max_length=self.tokenizer.model_max_length, truncation=True,
                                                    return_tensors='pt').input_ids
-            prompt_embeds = self.text_encoder(tokenized_prompts.to(device))[0]
+            prompt_embeds = self._text_states(tokenized_prompts.to(device))
         prompt_embeds = prompt_embeds.to(device).float()
         bs_embed, seq_len, _ = prompt_embeds.shape
         prompt_embeds = prompt_embeds.repeat(1, num_images_per_prompt, 1)
