@@ -23,6 +23,7 @@ SIGNATURES = {
     'da_gemm_tn_wgrad': [_vp, _l, _vp, _l, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _l, _vp],
     'da_gemm_tn_variant_for': [_i, _i, _i, _i, _i, _i, _i, _i, _i],
     'da_attn_fwd': [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _fp, _i, _i, _i, _i, _f, _vp],
+    'da_attn_fwd_causal': [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _fp, _i, _i, _i, _f, _vp],
     'da_attn_bwd': [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _fp, _fp, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i,
                     _f, _vp],
     'da_norm_scratch_floats': [_i, _i, _i],
@@ -36,6 +37,7 @@ SIGNATURES = {
     'da_geglu_fwd': [_vp, _l, _vp, _l, _i, _i, _vp],
     'da_geglu_bwd': [_vp, _l, _vp, _l, _vp, _l, _i, _i, _vp],
     'da_silu_fwd': [_vp, _l, _vp, _l, _i, _i, _vp],
+    'da_gelu_fwd': [_vp, _l, _vp, _l, _i, _i, _vp],
     'da_silu_bwd': [_vp, _l, _vp, _l, _vp, _l, _i, _i, _vp],
     'da_add': [_vp, _l, _vp, _l, _vp, _l, _i, _i, _vp],
     'da_copy2d': [_vp, _l, _vp, _l, _i, _i, _vp],

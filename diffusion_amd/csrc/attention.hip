@@ -118,6 +118,9 @@ DEVINL int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * 
 // ------------------------------------------------------------------------------------------------
 constexpr int FW_STAGE = 64 * 128 + 64 * TR_LD;
 
+// CAUSAL (the text encoder's self-attention, Nq == Nk): key j contributes to query q only for j <= q - every tile is
+// masked per lane like the ragged tail, and tiles wholly above a workgroup's last query are skipped.
+template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * FW_STAGE, dynamic: see attn_bwd_dkv_kernel
   const int tid = threadIdx.x, lane = tid & 63;
@@ -138,7 +141,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
   float m = -INFINITY, l = 0.f;
 
-  const int nt = (p.Nk + 63) / 64;
+  // causal: keys past the workgroup's last query are never needed
+  const int nk_eff = CAUSAL ? min(p.Nk, blk * 128 + 128) : p.Nk;
+  const int nt = (nk_eff + 63) / 64;
   // K / V tiles (64 keys) reach LDS by DMA, one tile ahead into the stage the previous step released: K as the row image,
   // V as the transposed-read image.  Wave w fills rows 8w..8w+7 and 32+8w..32+8w+7 of both.
   const int drow = wave * 8 + (lane >> 3), pc = lane & 7;
@@ -194,11 +199,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       tr_frag_issue(vto, 32 + 16 * s2, 32, lane, tv[s2][3][0], tv[s2][3][1]);
     }
     if constexpr (TAIL) {
+      const int klim = CAUSAL ? min(p.Nk, q + 1) : p.Nk;  // first key this lane's query does not see
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         int key = t * 64 + acc_row(i, lane);
-        if (key >= p.Nk) s0[i] = -INFINITY;
-        if (key + 32 >= p.Nk) s1[i] = -INFINITY;
+        if (key >= klim) s0[i] = -INFINITY;
+        if (key + 32 >= klim) s1[i] = -INFINITY;
       }
     }
     float mx = fmaxf(s0[0], s1[0]);
@@ -241,9 +247,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
     sync_tile();
   };
-  const int nfull = p.Nk / 64;
-  for (int t = 0; t < nfull; ++t) step(t, std::false_type{});
-  if (nfull < nt) step(nfull, std::true_type{});
+  if constexpr (CAUSAL) {  // every tile takes the masking step
+    for (int t = 0; t < nt; ++t) step(t, std::true_type{});
+  } else {
+    const int nfull = p.Nk / 64;
+    for (int t = 0; t < nfull; ++t) step(t, std::false_type{});
+    if (nfull < nt) step(nfull, std::true_type{});
+  }
   const float lt = l + xor32(l);
   const float inv = 1.0f / lt;
   if (qv) {
@@ -561,7 +571,22 @@ extern "C" int da_attn_fwd(const void* Q, long ldq, const void* K, long ldk, con
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
   p.scale = scale; p.sc = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 2 * FW_STAGE, stream, p);
+  hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((Nq + 127) / 128, H, B), dim3(256), 2 * FW_STAGE, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+extern "C" int da_attn_fwd_causal(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
+                                  long ldo, float* L2, int B, int H, int N, float scale, hipStream_t stream) {
+  DA_CLEAR_ERR();
+  if (B <= 0 || H <= 0 || N <= 0) return DA_ERR_SHAPE;
+  if (check(ldq) || check(ldk) || check(ldv) || check(ldo)) return DA_ERR_SHAPE;
+  AttnParams p = {};
+  p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.Out = (bf16*)O; p.L2 = L2;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.B = B; p.H = H; p.Nq = N; p.Nk = N;
+  p.scale = scale; p.sc = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((N + 127) / 128, H, B), dim3(256), 2 * FW_STAGE, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

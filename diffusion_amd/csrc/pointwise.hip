@@ -62,6 +62,17 @@ __global__ void silu_fwd_kernel(const bf16* x, long ldx, bf16* y, long ldy, int 
     st8(y + row * ldy + 8 * v, o);
   }
 }
+// ---- erf-GELU on a 2-D strided tensor (the text encoder's MLP activation; forward only - the encoder is frozen)
+__global__ void gelu_fwd_kernel(const bf16* x, long ldx, bf16* y, long ldy, int nvec, long total) {
+  GRID_STRIDE(i, total) {
+    long row = i / nvec;
+    int v = (int)(i - row * nvec);
+    bf16x8 a = ld8(x + row * ldx + 8 * v), o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_f(bf2f(a[e])));
+    st8(y + row * ldy + 8 * v, o);
+  }
+}
 __global__ void silu_bwd_kernel(const bf16* x, long ldx, const bf16* dy, long lddy, bf16* dx, long lddx, int nvec,
                                 long total) {
   GRID_STRIDE(i, total) {
@@ -371,6 +382,16 @@ extern "C" int da_silu_fwd(const void* x, long ldx, void* y, long ldy, int M, in
   CHK8(C); CHK8(ldx); CHK8(ldy);
   long total = (long)M * (C >> 3);
   hipLaunchKernelGGL(silu_fwd_kernel, dim3(pw_blocks(total)), dim3(PW_BLOCK), 0, s, (const bf16*)x, ldx, (bf16*)y,
+                     ldy, C >> 3, total);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+extern "C" int da_gelu_fwd(const void* x, long ldx, void* y, long ldy, int M, int C, hipStream_t s) {
+  DA_CLEAR_ERR();
+  if (M <= 0 || C <= 0) return DA_ERR_SHAPE;
+  CHK8(C); CHK8(ldx); CHK8(ldy);
+  long total = (long)M * (C >> 3);
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(pw_blocks(total)), dim3(PW_BLOCK), 0, s, (const bf16*)x, ldx, (bf16*)y,
                      ldy, C >> 3, total);
   DA_CHECK_LAUNCH();
   return DA_OK;

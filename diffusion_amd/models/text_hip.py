@@ -6,8 +6,9 @@ final LayerNorm; ``CLIPTextModel.from_pretrained(..., subfolder='text_encoder')`
 pre-LN transformer - LayerNorm, q|k|v projection, 77-token causal attention, output projection + residual, LayerNorm,
 fc1, GELU, fc2 + residual - i.e. the op set the U-Net's transformer blocks already run on ``da_layernorm_fwd`` and
 ``da_gemm_nt`` (bias / residual epilogues).  This module walks the weights of the torch module through those kernels
-(bf16 activations, fp32 accumulation / statistics); the 77 x 77 causal attention core (head_dim 64, the flash kernels
-have no causal mask) and the element-wise GELU between fc1 and fc2 stay on torch.
+(bf16 activations, fp32 accumulation / statistics), the causal self-attention through ``da_attn_fwd_causal`` (the flash
+forward kernel with a per-query key limit; heads are 64-column slices of the fused q|k|v buffer, so nothing is transposed)
+and the MLP activation through ``da_gelu_fwd``.  Only the embedding gather is a torch op.
 tests/test_text_hip_gpu.py bounds the difference of the last hidden state against the fp32 torch module.
 """
 from __future__ import annotations
@@ -83,16 +84,23 @@ class TextEncoderHIP:
             ops.SPLITK_WS = torch.empty(32 * 1024 * 1024, device=self.dev, dtype=F32)
         h = (self.tok[ids] + self.pos[:T]).reshape(M, C).to(BF16)
         stats = torch.empty(2 * M, device=self.dev, dtype=F32)
+        l2 = torch.empty(B * H * T, device=self.dev, dtype=F32)
         for ly in self.layers:
             x = self._ln(h, ly['ln1'], stats)
             qkv = self._lin(x, ly['wqkv'], ly['bqkv'])
-            q, k, v = (qkv[:, j * C:(j + 1) * C].reshape(B, T, H, D).transpose(1, 2) for j in range(3))
-            o = F.scaled_dot_product_attention(q, k, v, is_causal=True)      # scale D**-0.5 = CLIP's q scaling
-            o = o.transpose(1, 2).reshape(M, C).contiguous()
+            o = torch.empty(M, C, device=self.dev, dtype=BF16)
+            if D == 64:   # heads are 64-column slices of the fused projection: no transposes (scale D**-0.5 = CLIP's q scaling)
+                ops.attn_fwd_causal(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, l2, B, H, T, D ** -0.5)
+            else:
+                q, k, v = (qkv[:, j * C:(j + 1) * C].reshape(B, T, H, D).transpose(1, 2) for j in range(3))
+                o = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(M, C).contiguous()
             h = self._lin(o, ly['wo'], ly['bo'], residual=h)
             x = self._ln(h, ly['ln2'], stats)
             f = self._lin(x, ly['w1'], ly['b1'])
-            f = F.gelu(f) if self.act == 'gelu' else f * torch.sigmoid(1.702 * f)
+            if self.act == 'gelu':
+                ops.gelu_fwd(f, f)
+            else:
+                f = f * torch.sigmoid(1.702 * f)
             h = self._lin(f, ly['w2'], ly['b2'], residual=h)
         y = self._ln(h, self.lnf, stats)
         return (y.view(B, T, C).float(),)

@@ -226,6 +226,19 @@ def attn_fwd(Q, K, V, O, L2, B, H, Nq, Nk, scale):
                   float(scale), _stream())
 
 
+def attn_fwd_causal(Q, K, V, O, L2, B, H, N, scale):
+    """causal self-attention (key j <= query q), forward only: the frozen text encoder"""
+    q, ldq = _mat(Q, BF16, 'Q')
+    k, ldk = _mat(K, BF16, 'K')
+    v, ldv = _mat(V, BF16, 'V')
+    o, ldo = _mat(O, BF16, 'O')
+    for t in (Q, K, V, O):
+        if tuple(t.shape) != (B * N, H * 64):
+            raise ValueError(f'attention operand shape {tuple(t.shape)} != {(B * N, H * 64)}')
+    _lib.call('da_attn_fwd_causal', q, ldq, k, ldk, v, ldv, o, ldo, _f32buf(L2, B * H * N, 'L2'), B, H, N, float(scale),
+              _stream())
+
+
 def attn_bwd(Q, K, V, O, dO, L2, Delta, dQ, dK, dV, B, H, Nq, Nk, scale):
     ptrs = []
     for t, n, nm in ((Q, Nq, 'Q'), (K, Nk, 'K'), (V, Nk, 'V'), (O, Nq, 'O'), (dO, Nq, 'dO')):
@@ -322,6 +335,12 @@ def silu_fwd(x, y):
     a, lda = _mat(x, BF16)
     b, ldb = _mat(y, BF16)
     _lib.call('da_silu_fwd', a, lda, b, ldb, x.shape[0], x.shape[1], _stream())
+
+
+def gelu_fwd(x, y):
+    a, lda = _mat(x, BF16)
+    b, ldb = _mat(y, BF16)
+    _lib.call('da_gelu_fwd', a, lda, b, ldb, x.shape[0], x.shape[1], _stream())
 
 
 def silu_bwd(x, dy, dx):

@@ -94,7 +94,11 @@ int da_gemm_tn_variant_for(int M, int N, int Cin, int Hin, int Win, int Hout, in
  * attention for attn1 (self) and attn2 (cross, Nk = 77). */
 int da_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O, long ldo,
                 float* L2, int B, int H, int Nq, int Nk, float scale, da_stream_t stream);
-/* backward of the above; Delta[B][H][Nq] is scratch (rowsum(dO*O)). */
+/* the same with a causal mask (key j <= query q), Nq == Nk == N: the self-attention of the frozen text encoder
+ * (transformers CLIPTextModel behind stable_diffusion.py:168,172); forward only. */
+int da_attn_fwd_causal(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O, long ldo,
+                       float* L2, int B, int H, int N, float scale, da_stream_t stream);
+/* backward of da_attn_fwd; Delta[B][H][Nq] is scratch (rowsum(dO*O)). */
 int da_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const void* O, long ldo,
                 const void* dO, long lddo, const float* L2, float* Delta, void* dQ, long lddq, void* dK, long lddk,
                 void* dV, long lddv, int B, int H, int Nq, int Nk, float scale, da_stream_t stream);
@@ -137,6 +141,8 @@ int da_geglu_bwd(const void* in, long ldi, const void* dout, long lddo, void* di
 
 /* SiLU on the timestep embedding (ResnetBlock2D nonlinearity(temb), TimestepEmbedding act) */
 int da_silu_fwd(const void* x, long ldx, void* y, long ldy, int M, int C, da_stream_t stream);
+/* erf-GELU (the text encoder's MLP activation, CLIPTextConfig.hidden_act = "gelu"); forward only */
+int da_gelu_fwd(const void* x, long ldx, void* y, long ldy, int M, int C, da_stream_t stream);
 int da_silu_bwd(const void* x, long ldx, const void* dy, long lddy, void* dx, long lddx, int M, int C,
                 da_stream_t stream);
 

@@ -638,3 +638,25 @@ def test_adamw_and_cast(ops, dev):
     d = torch.empty(n, device=dev, dtype=BF)
     ops.cast_f32_bf16(p, d)
     assert torch.equal(d, p.to(BF))
+
+
+@pytest.mark.parametrize('B,H,N', [(3, 2, 77), (2, 1, 200), (1, 3, 128)])
+def test_attention_fwd_causal(ops, dev, B, H, N):
+    """da_attn_fwd_causal == softmax over keys j <= q (the text encoder's self-attention), strided q|k|v slices."""
+    C = H * 64
+    qkv = rnd(B * N, 3 * C, dev=dev, seed=N).to(BF)
+    o = torch.zeros(B * N, C, device=dev, dtype=BF)
+    l2 = torch.empty(B * H * N, device=dev)
+    ops.attn_fwd_causal(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, l2, B, H, N, 0.125)
+    q, k, v = (qkv[:, j * C:(j + 1) * C].float().reshape(B, N, H, 64).transpose(1, 2) for j in range(3))
+    ref = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(B * N, C)
+    check(o, ref, what='causal attention')
+
+
+def test_gelu_fwd(ops, dev):
+    x = rnd(100, 4096, dev=dev, seed=1, scale=2.0).to(BF)
+    y = torch.empty_like(x)
+    ops.gelu_fwd(x, y)
+    check(y, F.gelu(x.float()), what='gelu')
+    ops.gelu_fwd(x, x)      # in place
+    assert torch.equal(x, y)
