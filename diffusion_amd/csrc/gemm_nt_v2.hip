@@ -835,6 +835,7 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
   if (variant == 12) return launch_v2<4, 5, 4, 4, 64>(p, splits, ws, stream);  // 256 x 320 x 64, 16 waves (4 / SIMD)
   if (variant == 15) return launch_v2<1, 5, 8, 2, 64, 32>(p, splits, ws, stream);     // 256 x 320 x 64, 16 waves as 8 x 2, 32x32x16 MFMA
   if (variant == 16) return launch_v2<2, 5, 4, 2, 64, 32>(p, splits, ws, stream);     // 256 x 320 x 64, 8 waves as 4 x 2 (64 x 160 each), 32x32x16 MFMA
+  if (variant == 18) return launch_v2<3, 4, 8, 2, 64>(p, splits, ws, stream);         // 384 x 128 x 64, 16 waves as 8 x 2: N = 128 (VAE encoder, first level)
   if (variant == 14) return launch_v2<4, 4, 4, 4, 64>(p, splits, ws, stream);      // 256 x 256 x 64, 16 waves: N = 256 / 512 (VAE encoder)
   return variant == 5 ? launch_v2<4, 5, 4, 2, 64>(p, splits, ws, stream) : launch_v2<4, 4, 4, 2, 64>(p, splits, ws, stream);
 }

@@ -141,7 +141,8 @@ def gemm_nt(A, W, out, g: Geom, *, bias=None, rowbias=None, residual=None, alpha
         v = _lib.load().da_gemm_nt_variant_for(M, N, K, Cin, SPLITK_WS.numel() if SPLITK_WS is not None else 0)
         name = {1: 'gemm_nt_kernel', 4: 'gemm_nt2_kernel<4,4,4,2>', 5: 'gemm_nt2_kernel<4,5,4,2>',
                 10: 'gemm_nt2_kernel<8,5,2,4>', 11: 'gemm_nt2_kernel<4,10,2,2>', 12: 'gemm_nt2_kernel<4,5,4,4>',
-                14: 'gemm_nt2_kernel<4,4,4,4>', 15: 'gemm_nt2_kernel<1,5,8,2,mf32>', 16: 'gemm_nt2_kernel<2,5,4,2,mf32>'}[v]
+                14: 'gemm_nt2_kernel<4,4,4,4>', 15: 'gemm_nt2_kernel<1,5,8,2,mf32>', 16: 'gemm_nt2_kernel<2,5,4,2,mf32>',
+                18: 'gemm_nt2_kernel<3,4,8,2>'}[v]
     with _Timed(name, flops, (M, N, K, g.ksize, g.mode)):
         _lib.call('da_gemm_nt', a_ptr, lda, w_ptr, c_ptr, ldc, _vec(bias, N, 'bias'), rb_ptr, ldrb, r_ptr, ldr, M, N,
                   K, Cin, g.Hin, g.Win, g.Hout, g.Wout, g.ksize, g.mode, int(out_fp32), float(alpha),

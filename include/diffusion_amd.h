@@ -60,7 +60,8 @@ int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* 
 /* tuning / test hooks (process-wide; 0 is always the shipped behaviour unless noted).  Returns DA_ERR_SHAPE for unknown keys.
  *   "gemm_nt_variant"   0 auto | 1 the 128x128 register-staged kernel | 4 / 5 / 10 / 14 / 12 force the 256x128 / 256x160 /
  *                       256x320 (8-wave) / 256x256 / 256x320 (16-wave) LDS-DMA form where eligible (Cin % 64 == 0) |
- *                       11 the 4-wave 128x320x32 form | 15 / 16 the 256x320 tile on 32x32x16 MFMAs (16 waves as 8x2 / 8 waves as 4x2)
+ *                       11 the 4-wave 128x320x32 form | 15 / 16 the 256x320 tile on 32x32x16 MFMAs (16 waves as 8x2 / 8 waves as 4x2) |
+ *                       18 the 16-wave 384x128 form (N <= 128: VAE encoder)
  *   "gemm_nt_mfma32"    0 (default) never | -1 variant 12 becomes 15 for K <= 320 | 1 always
  *   "gemm_nt_dispatch"  1 (default) cost model over (tile form, split-K) | 0 the round-1 fill thresholds
  *   "gemm_nt_korder"    1 (default) 3x3 K loop walks a 64-channel chunk through its 9 taps | 0 tap-major

@@ -205,7 +205,7 @@ def test_gemm_nt_persistent_tile_walk(ops, dev, grid):
     check(ref[2], h[:, :inner] * F.gelu(h[:, inner:]), what='persistent geglu')
 
 
-@pytest.mark.parametrize('variant', [4, 5, 10, 11, 12, 14, 15, 16])
+@pytest.mark.parametrize('variant', [4, 5, 10, 11, 12, 14, 15, 16, 18])
 def test_gemm_nt_v2_variants(ops, dev, variant):
     """The 256x(128|160) LDS-DMA kernel forced on: linear + every conv mode, ragged M / N tails, fused epilogue."""
     ops.set_option('gemm_nt_variant', variant)
