@@ -250,6 +250,8 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
 extern int g_tn_variant;  // gemm_tn.hip
 extern int g_nt_korder;  // gemm_nt_v2.hip
 extern int g_nt_persist;
+extern int g_reserve_cus;
+int da_usable_cus(int cus);
 static int g_nt_variant = 0;
 static int g_nt_mfma32 = 0;   // da_set_option("gemm_nt_mfma32", 0 never | -1 for K <= 320 | 1 always): the 256x320 form on
                               // v_mfma_f32_32x32x16_bf16 (variant 15) where the cost model picks variant 12
@@ -306,13 +308,14 @@ static int pick_nt_variant(int M, int N, int K, int Cin, long ws_floats, int* sp
   static const Form forms[] = {{12, 256, 320, 1.5, 8.0}, {14, 256, 256, 1.3, 8.0}, {5, 256, 160, 1.16, 6.0}, {18, 384, 128, 1.37, 8.0},
                                {4, 256, 128, 1.07, 5.0}};
   const int nk = K / 64;
+  const int ncu = da_usable_cus(256);  // da_set_option("reserve_cus")
   double best = 1e30;
   int best_v = 4, best_s = 1;
   for (const Form& f : forms) {
     const long tiles = ((M + f.bm - 1) / f.bm) * ((N + f.bn - 1) / f.bn);
     for (int s = 1; s <= (g_nt_splitk ? 8 : 1); ++s) {
       if (s > 1 && (nk / s < 4 || (long)s * M * N > ws_floats)) break;
-      const long rounds = (tiles * s + 255) / 256;
+      const long rounds = (tiles * s + ncu - 1) / ncu;
       const int steps = (nk + s - 1) / s;
       double t = (double)rounds * (steps * f.step_us + f.fixed_us);
       if (s > 1) t += 20.0 + ((double)s * M * N * 4.0 + (double)M * N * 2.0) / 5.0e6;  // finalize launch + slab traffic at ~5 TB/s
@@ -363,6 +366,11 @@ extern "C" int da_set_option(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_tn_variant")) {
     g_tn_variant = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "reserve_cus")) {
+    if (value < 0 || value > 128) return DA_ERR_SHAPE;
+    g_reserve_cus = value;
     return DA_OK;
   }
   return DA_ERR_SHAPE;

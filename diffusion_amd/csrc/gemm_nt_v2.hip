@@ -18,6 +18,15 @@
 
 
 int g_nt_persist = -1;  // da_set_option("gemm_nt_persist", n): resident workgroups of the persistent forms (-1 = #CUs, 0 = off)
+// da_set_option("reserve_cus", R): CUs left to somebody else - the RCCL channels of the gradient all-reduce that overlaps
+// backward in a multi-GPU job.  Every grid that is sized to ONE ROUND of the chip (the persistent tile walks here, the
+// weight-gradient pixel splits in gemm_tn_v2.hip, the cost model's round count in gemm_nt.hip) is sized to #CUs - R
+// instead, so that a CU taken by a collective does not push a whole-CU workgroup into a second round.  0 = whole chip.
+int g_reserve_cus = 0;
+int da_usable_cus(int cus) {
+  int n = cus - g_reserve_cus;
+  return n < 32 ? 32 : n;
+}
 
 namespace {
 
@@ -738,7 +747,7 @@ static int persistent_grid(int total_blocks) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return total_blocks;
     if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
-    n = cus[dev];
+    n = da_usable_cus(cus[dev]);
   }
   return total_blocks < n ? total_blocks : n;
 }

@@ -7,7 +7,8 @@
 // 4 waves as 2x2 with 4x4 v_mfma_f32_16x16x32_bf16 tiles each.  LDS rows are padded to 288 B so the
 // 8 rows a 32-lane half touches per transposed read land on disjoint banks.
 // The pixel range is split over `splits` workgroups (small Cout x K layers have too few tiles to fill
-// 256 CUs); partial tiles are accumulated into the fp32 gradient buffer with global_atomic_add_f32.
+// 256 CUs); partial tiles are stored as fp32 slabs in the caller's workspace and summed in a fixed order by
+// tn1_slab_reduce_kernel (global_atomic_add_f32 only when no workspace was passed).
 #include "common.hpp"
 #include "diffusion_amd.h"
 
@@ -22,6 +23,7 @@ struct GemmTNParams {
   int Hin, Win, Hout, Wout, ksize, mode;
   FastDiv div_hw, div_w;
   int tiles_n, tiles_k, splits, m_per_split;
+  float* slab;  // splits > 1 with a workspace: partial tiles [tile][split][128][128] fp32, summed by tn1_slab_reduce_kernel
 };
 
 constexpr int TN_BM = 32;                 // pixels per step
@@ -160,9 +162,39 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4 + e;
-        if (n < p.N && kc < p.Kt) unsafeAtomicAdd(p.dW + (long)n * p.Kt + kc, acc[i][j][e]);
+        if (p.slab) {
+          const int nl = wn * 64 + i * 16 + (lane >> 4) * 4 + e, kl = wk * 64 + j * 16 + (lane & 15);
+          p.slab[(((long)(tn * p.tiles_k + tk) * p.splits + split) * 128 + nl) * 128 + kl] = acc[i][j][e];
+        } else if (n < p.N && kc < p.Kt) {
+          float* dst = p.dW + (long)n * p.Kt + kc;
+          if (p.splits == 1) *dst += acc[i][j][e];   // sole owner of the tile
+          else unsafeAtomicAdd(dst, acc[i][j][e]);   // no workspace: order-dependent last bits
+        }
       }
     }
+}
+
+// dW[n][k'] += sum_split slab[tile(n, k')][split][n % 128][k' % 128], 4 consecutive k' per thread, eight chains, fixed order
+__global__ __launch_bounds__(256) void tn1_slab_reduce_kernel(GemmTNParams p) {
+  const int kq = p.Kt >> 2;
+  const long total = (long)p.N * kq;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / kq);
+    const int kc = (int)(i - (long)n * kq) * 4;
+    const int tn = n >> 7, tk = kc >> 7;
+    const float* src = p.slab + (((long)(tn * p.tiles_k + tk) * p.splits) * 128 + (n & 127)) * 128 + (kc & 127);
+    f32x4 acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int sp = 0;
+    for (; sp + 7 < p.splits; sp += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += *reinterpret_cast<const f32x4*>(src + (long)(sp + u) * 128 * 128);
+    }
+    for (int u = 0; sp < p.splits; ++sp, ++u) acc[u & 7] += *reinterpret_cast<const f32x4*>(src + (long)sp * 128 * 128);
+    f32x4* dst = reinterpret_cast<f32x4*>(p.dW + (long)n * p.Kt + kc);
+    *dst += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  }
 }
 
 }  // namespace
@@ -228,7 +260,16 @@ extern "C" int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long l
   splits = (M + mps - 1) / mps;
   p.splits = splits;
   p.m_per_split = mps;
+  // split tiles meet in a slab + fixed-order reduce when the caller passed a workspace (reproducible), else in atomics
+  p.slab = nullptr;
+  if (splits > 1 && split_ws && (long)tiles * splits * 128 * 128 <= split_ws_floats && (p.Kt & 3) == 0) p.slab = split_ws;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 0, stream, p);
   DA_CHECK_LAUNCH();
+  if (p.slab) {
+    long blocks = ((long)p.N * (p.Kt >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(tn1_slab_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, p);
+    DA_CHECK_LAUNCH();
+  }
   return DA_OK;
 }

@@ -15,6 +15,8 @@
 #include "common.hpp"
 #include "diffusion_amd.h"
 
+int da_usable_cus(int cus);  // gemm_nt_v2.hip: #CUs less da_set_option("reserve_cus")
+
 namespace {
 
 struct GemmTN2Params {
@@ -29,6 +31,7 @@ struct GemmTN2Params {
   int tiles_n, tiles_k, splits, m_per_split;
   float* slab;  // split > 1 with a workspace: tile partials are STORED here, [tile][split][320][BK] fp32, and summed
                // into dW by tn_slab_reduce_kernel (no atomics; fixed summation order)
+  float* bslab;  // the bias-gradient partials of the same splits, [tn][split][320] fp32 (behind the tile slabs)
   int period;  // FAST path: the border pattern of a lane's X rows repeats every `period` 64-pixel steps
 };
 
@@ -393,8 +396,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     for (int i = 0; i < 5; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int n = n0 + wa * 80 + i * 16 + (lane >> 4) * 4 + e;
-        if (n < p.N) unsafeAtomicAdd(p.dbias + n, accb[i][e]);
+        const int nl = wa * 80 + i * 16 + (lane >> 4) * 4 + e, n = n0 + nl;
+        if (p.slab && p.splits > 1) p.bslab[((long)tn * p.splits + split) * T2_BN + nl] = accb[i][e];  // summed by the reduce kernel
+        else if (n < p.N) {
+          if (p.splits == 1) p.dbias[n] += accb[i][e];  // the only workgroup with this (tn, tk == 0)
+          else unsafeAtomicAdd(p.dbias + n, accb[i][e]);  // no workspace: order-dependent last bits (as dW above)
+        }
       }
   }
 }
@@ -423,6 +430,20 @@ __global__ __launch_bounds__(256) void tn_slab_reduce_kernel(GemmTN2Params p) {
     f32x4* dst = reinterpret_cast<f32x4*>(p.dW + (long)n * p.Kt + kc);
     *dst += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
+  // bias gradient: dbias[n] += sum_split bslab[tn][split][n % 320]; 16 lanes share an n (splits l, l + 16, ...), then a
+  // fixed butterfly - the same additions in the same order every run
+  if (p.dbias) {
+    const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+    for (int n = blockIdx.x * 16 + grp; n < p.N; n += gridDim.x * 16) {
+      const int tn = n / T2_BN;
+      const float* src = p.bslab + ((long)tn * p.splits) * T2_BN + (n - tn * T2_BN);
+      float a = 0.f;
+      for (int sp = l; sp < p.splits; sp += 16) a += src[(long)sp * T2_BN];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
+      if (l == 0) p.dbias[n] += a;
+    }
+  }
 }
 
 template <int BK, bool FAST>
@@ -431,15 +452,17 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
   p.tiles_n = (p.N + T2_BN - 1) / T2_BN;
   p.tiles_k = (p.Kt + BK - 1) / BK;
   const int tiles = p.tiles_n * p.tiles_k;
-  // One 512-thread workgroup per CU; the pixel range is split into k parts so that tiles*k fills the 256 CUs.
-  //  * tiles >= 232 (>= 90 % of the CUs): k = 1 - the workgroup owns its tile, plain read-add-write, no atomics;
-  //  * otherwise the smallest k whose grid is (nearly) a whole number of 256-CU rounds (last round >= 90 % full),
-  //    capped so that the k extra fp32 atomic tile-writes (~1.3 TB/s chip-wide) stay below ~20 % of the GEMM time
+  // One 512-thread workgroup per CU; the pixel range is split into k parts so that tiles*k fills the CUs (256, less the
+  // ones da_set_option("reserve_cus") leaves to an overlapping collective).
+  //  * tiles >= 90 % of the CUs: k = 1 - the workgroup owns its tile, plain read-add-write, no slabs;
+  //  * otherwise the smallest k whose grid is (nearly) a whole number of rounds (last round >= 90 % full),
+  //    capped so that the k extra fp32 tile writes stay below ~20 % of the GEMM time
   //    (k <= M/6000) but never below one full round; fallback: the fullest grid within the cap.
+  const int ncu = da_usable_cus(256);
   int best = 1;
-  if (tiles < 232) {
+  if (tiles < (ncu * 29) / 32) {
     int kcap = p.M / 6000;
-    const int one_round = (256 + tiles - 1) / tiles;
+    const int one_round = (ncu + tiles - 1) / tiles;
     if (kcap < one_round) kcap = one_round;
     const int max_splits = p.M / 512 > 0 ? p.M / 512 : 1;
     if (kcap > max_splits) kcap = max_splits;
@@ -447,8 +470,8 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
     bool found = false;
     for (int k = 1; k <= kcap; ++k) {
       const long blocks = (long)tiles * k;
-      const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
-      if (eff >= 0.9 && blocks >= 250) {
+      const double eff = (double)blocks / (double)(((blocks + ncu - 1) / ncu) * ncu);
+      if (eff >= 0.9 && blocks >= ncu - 6) {
         best = k;
         found = true;
         break;
@@ -466,8 +489,15 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
   p.m_per_split = mps;
   static unsigned long long attr_done = 0;  // one bit per device
   if (da_ensure_dyn_smem((const void*)gemm_tn2_kernel<BK, FAST>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
-  p.slab = nullptr;
-  if (p.splits > 1 && ws && (long)tiles * p.splits * T2_BN * BK <= ws_floats && (p.Kt & 3) == 0) p.slab = ws;
+  p.slab = p.bslab = nullptr;
+  {
+    const long tile_floats = (long)tiles * p.splits * T2_BN * BK;
+    const long bias_floats = p.dbias ? (long)p.tiles_n * p.splits * T2_BN : 0;
+    if (p.splits > 1 && ws && tile_floats + bias_floats <= ws_floats && (p.Kt & 3) == 0) {
+      p.slab = ws;
+      p.bslab = ws + tile_floats;
+    }
+  }
   hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST>), dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   if (p.slab) {
@@ -509,7 +539,7 @@ int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X
   p.div_w = make_fastdiv((unsigned)Wout);
   p.div_cin = make_fastdiv((unsigned)Cin);
   p.tiles_n = p.tiles_k = p.splits = p.m_per_split = 0;
-  p.slab = nullptr;
+  p.slab = p.bslab = nullptr;
   (void)variant;  // the 320x256 instantiation (160 accumulators) spills on gfx950 and lost to 320x192 everywhere
   p.period = da_gemm_tn_v2_fast_period(M, N, Hin, Win, Hout, Wout, mode);
   return p.period ? launch_tn2<192, true>(p, ws, ws_floats, stream) : launch_tn2<192, false>(p, ws, ws_floats, stream);

@@ -1,8 +1,8 @@
 // GroupNorm / LayerNorm forward+backward and per-channel reductions on NHWC bf16 activations
 // (SURVEY.md K5, K7 and the bias-gradient column sums).  All HBM-bound: 16-B vector accesses along the
 // channel axis, fp32 statistics, wave64 shuffles / LDS for the reductions, and NO atomics - every
-// reduction is a fixed-order two-stage sum (partials per pixel chunk -> finalize), so results are
-// bitwise reproducible run to run.
+// reduction is a fixed-order two-stage sum (partials per pixel chunk -> one finalize block per channel slice), so
+// results - the norm-affine and bias gradients included - are bitwise reproducible run to run.
 //
 // chan_reduce<MODE>: each thread owns 8 consecutive channels and walks pixels; per-(image, channel)
 //   partial sums of two quantities are written per pixel chunk:
@@ -350,83 +350,110 @@ __global__ void gn_bwd_apply_kernel(const bf16* X, long ldx, const bf16* DY, lon
 }
 
 // out1[c] += sum_rows partial[row][c][0] ; out2[c] += sum_rows partial[row][c][1]
-// block = 32 channels x 8 row-lanes (float2 loads, 256 B per row segment), LDS tree over the row-lanes; the rows are
-// sliced over blockIdx.y (a C/32-block grid alone left this at ~16 us per call, 114 calls per step) and the slices
-// meet in fp32 atomics, like the split wgrad tiles do
-__global__ __launch_bounds__(256) void chan_sum_finalize_kernel(const float* partial, int nrows, int C, float* out1,
-                                                                float* out2) {
-  __shared__ float sh[8][32][2];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
-  const int per = (nrows + gridDim.y - 1) / gridDim.y;
-  const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
+// ONE stage, fixed order, no atomics (bitwise reproducible): a block owns 16 channels (128-B row segments, float2 loads)
+// and spreads the rows over 64 row-lanes, each with four independent chains (eight loads in flight per thread); the
+// row-lanes meet in LDS and thread (0, cx) adds them in lane order.  The earlier form sliced the rows over blockIdx.y and
+// let the slices meet in fp32 atomics (order-dependent last bits in every norm / bias gradient).
+constexpr int CSF_CH = 16, CSF_RL = 64;
+__global__ __launch_bounds__(CSF_CH * CSF_RL) void chan_sum_finalize_kernel(const float* partial, int nrows, int C,
+                                                                            float* out1, float* out2) {
+  __shared__ float sh[CSF_RL][CSF_CH][2];
+  const int cx = threadIdx.x % CSF_CH, ry = threadIdx.x / CSF_CH;
+  const int c = blockIdx.x * CSF_CH + cx;
   float a = 0.f, q = 0.f;
   if (c < C) {
     const float2* pp = reinterpret_cast<const float2*>(partial) + c;
-    int k = r0 + ry;
-    for (; k + 24 < r1; k += 32) {
-      float2 v0 = pp[(long)k * C], v1 = pp[(long)(k + 8) * C], v2 = pp[(long)(k + 16) * C], v3 = pp[(long)(k + 24) * C];
-      a += (v0.x + v1.x) + (v2.x + v3.x);
-      q += (v0.y + v1.y) + (v2.y + v3.y);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+    int k = ry;
+    for (; k + 3 * CSF_RL < nrows; k += 4 * CSF_RL) {
+      const float2 v0 = pp[(long)k * C], v1 = pp[(long)(k + CSF_RL) * C], v2 = pp[(long)(k + 2 * CSF_RL) * C],
+                   v3 = pp[(long)(k + 3 * CSF_RL) * C];
+      a0 += v0.x; q0 += v0.y;
+      a1 += v1.x; q1 += v1.y;
+      a2 += v2.x; q2 += v2.y;
+      a3 += v3.x; q3 += v3.y;
     }
-    for (; k < r1; k += 8) {
-      float2 v = pp[(long)k * C];
-      a += v.x;
-      q += v.y;
+    for (; k < nrows; k += CSF_RL) {
+      const float2 v = pp[(long)k * C];
+      a0 += v.x;
+      q0 += v.y;
     }
+    a = (a0 + a1) + (a2 + a3);
+    q = (q0 + q1) + (q2 + q3);
   }
   sh[ry][cx][0] = a;
   sh[ry][cx][1] = q;
   __syncthreads();
-  if (ry == 0 && c < C) {
+  // 64 row-lanes -> 8 -> 1, every level in index order
+  float la = 0.f, lq = 0.f;
+  if (ry < 8) {
 #pragma unroll
-    for (int j = 1; j < 8; ++j) {
-      a += sh[j][cx][0];
-      q += sh[j][cx][1];
+    for (int j = 0; j < 8; ++j) {
+      la += sh[ry * 8 + j][cx][0];
+      lq += sh[ry * 8 + j][cx][1];
     }
-    if (gridDim.y == 1) {
-      if (out1) out1[c] += a;
-      if (out2) out2[c] += q;
-    } else {
-      if (out1) unsafeAtomicAdd(out1 + c, a);
-      if (out2) unsafeAtomicAdd(out2 + c, q);
+  }
+  __syncthreads();
+  if (ry < 8) {
+    sh[ry][cx][0] = la;
+    sh[ry][cx][1] = lq;
+  }
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    float ta = 0.f, tq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ta += sh[j][cx][0];
+      tq += sh[j][cx][1];
     }
+    if (out1) out1[c] += ta;
+    if (out2) out2[c] += tq;
   }
 }
 
 static inline dim3 chan_sum_grid(int nrows, int C) {
-  int y = nrows / 64;  // >= 8 rows per row-lane and slice
-  if (y > 16) y = 16;
-  if (y < 1) y = 1;
-  return dim3((C + 31) / 32, y);
+  (void)nrows;
+  return dim3((C + CSF_CH - 1) / CSF_CH);
 }
 
 // out[b][c] = sum_chunks partial[b][chunk][c][0] (bf16, strided) ; db[c] += sum_b out[b][c] (fp32)
-// block = 32 channels x 8 image-lanes over the images of slice blockIdx.y (slices meet in db through fp32 atomics)
-__global__ __launch_bounds__(256) void image_colsum_finalize_kernel(const float* partial, bf16* out, long ldo, float* db,
-                                                                    int B, int nchunks, int C) {
-  __shared__ float sh[8][32];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
-  const int per = (B + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+// block = 16 channels x 64 image-lanes; the image-lanes meet in LDS in lane order (no atomics, reproducible)
+__global__ __launch_bounds__(CSF_CH * CSF_RL) void image_colsum_finalize_kernel(const float* partial, bf16* out, long ldo,
+                                                                                float* db, int B, int nchunks, int C) {
+  __shared__ float sh[CSF_RL][CSF_CH];
+  const int cx = threadIdx.x % CSF_CH, ry = threadIdx.x / CSF_CH;
+  const int c = blockIdx.x * CSF_CH + cx;
   float tot = 0.f;
   if (c < C) {
-    for (int b = b0 + ry; b < b1; b += 8) {
+    for (int b = ry; b < B; b += CSF_RL) {
       const float* pp = partial + ((long)b * nchunks * C + c) * 2;
-      float a = 0.f;
-      for (int k = 0; k < nchunks; ++k) a += pp[(long)k * C * 2];
+      float a0 = 0.f, a1 = 0.f;
+      int k = 0;
+      for (; k + 1 < nchunks; k += 2) {
+        a0 += pp[(long)k * C * 2];
+        a1 += pp[(long)(k + 1) * C * 2];
+      }
+      if (k < nchunks) a0 += pp[(long)k * C * 2];
+      const float a = a0 + a1;
       out[(long)b * ldo + c] = f2bf(a);
       tot += a;
     }
   }
   sh[ry][cx] = tot;
   __syncthreads();
-  if (ry == 0 && c < C && db) {
+  float lt = 0.f;
+  if (ry < 8) {
 #pragma unroll
-    for (int j = 1; j < 8; ++j) tot += sh[j][cx];
-    if (gridDim.y == 1) db[c] += tot;
-    else unsafeAtomicAdd(db + c, tot);
+    for (int j = 0; j < 8; ++j) lt += sh[ry * 8 + j][cx];
+  }
+  __syncthreads();
+  if (ry < 8) sh[ry][cx] = lt;
+  __syncthreads();
+  if (ry == 0 && c < C && db) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += sh[j][cx];
+    db[c] += t;
   }
 }
 
@@ -791,7 +818,7 @@ extern "C" int da_groupnorm_bwd(const void* X, long ldx, const void* dY, long ld
                      gamma, coef, C, G, C / G, p.nchunks, HW);
   DA_CHECK_LAUNCH();
   // dgamma[c] += sum_b s2, dbeta[c] += sum_b s1
-  hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid(B * p.nchunks, C), dim3(256), 0, stream, scratch,
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid(B * p.nchunks, C), dim3(CSF_CH * CSF_RL), 0, stream, scratch,
                      B * p.nchunks, C, dbeta, dgamma);
   DA_CHECK_LAUNCH();
   GnApplyParams ap = {};
@@ -815,7 +842,7 @@ extern "C" int da_colsum_accum(const void* X, long ldx, float* out, float* scrat
   p.nchunks = n;
   int rc = launch_chan_reduce(2, p, 1, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid(n, C), dim3(256), 0, stream, scratch, n, C, out,
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid(n, C), dim3(CSF_CH * CSF_RL), 0, stream, scratch, n, C, out,
                      (float*)nullptr);
   DA_CHECK_LAUNCH();
   return DA_OK;
@@ -830,11 +857,8 @@ extern "C" int da_image_colsum(const void* X, long ldx, void* out, long ldo, flo
   p.HW = HW; p.C = C; p.G = 1; p.cpg = C; p.nchunks = pick_chunks(B, HW);
   int rc = launch_chan_reduce(2, p, B, stream);
   if (rc) return rc;
-  int ys = B / 8;  // one image per image-lane and slice
-  if (ys > 32) ys = 32;
-  if (ys < 1) ys = 1;
-  hipLaunchKernelGGL(image_colsum_finalize_kernel, dim3((C + 31) / 32, ys), dim3(256), 0, stream, scratch, (bf16*)out,
-                     ldo, db, B, p.nchunks, C);
+  hipLaunchKernelGGL(image_colsum_finalize_kernel, dim3((C + CSF_CH - 1) / CSF_CH), dim3(CSF_CH * CSF_RL), 0, stream,
+                     scratch, (bf16*)out, ldo, db, B, p.nchunks, C);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -887,7 +911,7 @@ extern "C" int da_layernorm_bwd(const void* X, long ldx, const void* dY, long ld
     if (C == 320) LN_BWD5(8); else if (C == 640) LN_BWD5(16); else LN_BWD5(32);
 #undef LN_BWD5
     DA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid((int)b5, C), dim3(256), 0, stream, scratch, (int)b5, C,
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid((int)b5, C), dim3(CSF_CH * CSF_RL), 0, stream, scratch, (int)b5, C,
                        dgamma, dbeta);
     DA_CHECK_LAUNCH();
     return DA_OK;
@@ -898,7 +922,7 @@ extern "C" int da_layernorm_bwd(const void* X, long ldx, const void* dY, long ld
                      (const bf16*)X, ldx, (const bf16*)dY, lddy, (const bf16*)Radd, ldr, (bf16*)dX, lddx, gamma,
                      mean_rstd, scratch, M, C);
   DA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid(blocks, C), dim3(256), 0, stream, scratch, blocks, C,
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid(blocks, C), dim3(CSF_CH * CSF_RL), 0, stream, scratch, blocks, C,
                      dgamma, dbeta);
   DA_CHECK_LAUNCH();
   return DA_OK;

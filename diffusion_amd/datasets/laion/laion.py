@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence, Union
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader, Dataset, DistributedSampler, RandomSampler, SequentialSampler
+from torch.utils.data import DataLoader, Dataset, DistributedSampler, SequentialSampler
 
 
 class SyntheticLAIONDataset(Dataset):
@@ -174,10 +174,11 @@ def build_streaming_laion_dataloader(
         sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed,
                                      drop_last=drop_last)
     elif shuffle:
-        sampler = RandomSampler(dataset, generator=torch.Generator().manual_seed(seed))
+        sampler = EpochRandomSampler(dataset, seed=seed)
     else:
         sampler = SequentialSampler(dataset)
-    return EpochDataLoader(dataset=dataset, batch_size=batch_size, sampler=sampler, drop_last=drop_last, **dataloader_kwargs)
+    return EpochDataLoader(dataset=dataset, batch_sampler=ResumableBatchSampler(sampler, batch_size, drop_last),
+                           **dataloader_kwargs)
 
 
 def _as_list(x) -> List[str]:
@@ -189,19 +190,76 @@ def _as_list(x) -> List[str]:
     return [str(d) for d in x if d]
 
 
+class EpochRandomSampler(torch.utils.data.Sampler):
+    """Single-process shuffle: the permutation of epoch e is a pure function of (seed, e) - like DistributedSampler's -
+    so a resumed run reproduces the epoch it stopped in instead of continuing a generator it no longer has."""
+
+    def __init__(self, data_source, seed: int = 0):
+        self.n = len(data_source)
+        self.seed = int(seed)
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        return iter(torch.randperm(self.n, generator=g).tolist())
+
+    def __len__(self):
+        return self.n
+
+
+class ResumableBatchSampler(torch.utils.data.Sampler):
+    """torch's BatchSampler plus ``skip``: the next iterator drops its first ``skip`` batches at INDEX level (no sample is
+    loaded for them) - how a resumed run continues in the middle of an epoch (streaming's StreamingDataset resumes
+    mid-epoch from its state dict; reference laion.py:167-180 / SD-2-base-256.yaml:91-94 autoresume)."""
+
+    def __init__(self, sampler, batch_size: int, drop_last: bool):
+        self.sampler, self.batch_size, self.drop_last = sampler, int(batch_size), bool(drop_last)
+        self.skip = 0
+
+    def __iter__(self):
+        skip, self.skip = self.skip, 0
+        batch, nb = [], 0
+        for idx in self.sampler:
+            batch.append(idx)
+            if len(batch) == self.batch_size:
+                if nb >= skip:
+                    yield batch
+                nb += 1
+                batch = []
+        if batch and not self.drop_last and nb >= skip:
+            yield batch
+
+    def __len__(self):
+        n = len(self.sampler)
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+
 class EpochDataLoader(DataLoader):
-    """DataLoader that advances its sampler's epoch each time a new iterator is made (a DistributedSampler reshuffles
-    only when told the epoch); ``set_epoch`` lets a resumed run continue the sequence."""
+    """DataLoader that advances its sampler's epoch each time a new iterator is made (the samplers reshuffle only when
+    told the epoch).  ``set_epoch(e, skip_batches=k)`` lets a resumed run continue the sequence: the next iterator is
+    epoch e without its first k batches."""
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self._next_epoch = 0
 
-    def set_epoch(self, epoch: int):
+    @property
+    def index_sampler(self):
+        return self.batch_sampler.sampler if isinstance(self.batch_sampler, ResumableBatchSampler) else self.sampler
+
+    def set_epoch(self, epoch: int, skip_batches: int = 0):
         self._next_epoch = int(epoch)
+        if isinstance(self.batch_sampler, ResumableBatchSampler):
+            self.batch_sampler.skip = int(skip_batches)
+        elif skip_batches:
+            raise ValueError('skip_batches needs a ResumableBatchSampler')
 
     def __iter__(self):
-        if hasattr(self.sampler, 'set_epoch'):
-            self.sampler.set_epoch(self._next_epoch)
+        smp = self.index_sampler
+        if hasattr(smp, 'set_epoch'):
+            smp.set_epoch(self._next_epoch)
         self._next_epoch += 1
         return super().__iter__()

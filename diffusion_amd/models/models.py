@@ -127,14 +127,19 @@ def stable_diffusion_2(
         if pretrained and not (te_dir and os.path.isdir(te_dir)):
             raise FileNotFoundError(f'pretrained=True but {te_dir} is missing: the frozen text encoder would be random')
         vae_hip = None
-        if os.environ.get('DA_VAE_HIP', '1') != '0':
+        # The HIP encoders compute in bf16 (activations and residual stream), i.e. at the precision class the caller asked
+        # for with encode_latents_in_fp16=True (the reference default, models.py:37).  With encode_latents_in_fp16=False
+        # the reference encodes the training targets in fp32: then the PyTorch-ROCm fp32 modules run unless the HIP
+        # encoders are asked for explicitly (DA_VAE_HIP=1 / DA_TEXT_HIP=1).
+        hip_default = '1' if encode_latents_in_fp16 else '0'
+        if os.environ.get('DA_VAE_HIP', hip_default) != '0':
             # the encoder half of the frozen VAE on the HIP kernels (models/vae_hip.py), built from the fp32 weights
             from .vae_hip import VAEEncoderHIP
             vae_hip = VAEEncoderHIP(vae.to('cuda'))
         vae = vae.to('cuda', dtype)
         text_encoder = build_text_encoder(te_dir, torch.float32, hidden_size=unet_config.cross_attention_dim).to('cuda')
         text_hip = None
-        if os.environ.get('DA_TEXT_HIP', '1') != '0' and text_encoder.config.hidden_size % 64 == 0 and \
+        if os.environ.get('DA_TEXT_HIP', hip_default) != '0' and text_encoder.config.hidden_size % 64 == 0 and \
                 text_encoder.config.hidden_size // text_encoder.config.num_attention_heads == 64:
             # the frozen text encoder on the HIP kernels (models/text_hip.py), built from the fp32 weights
             from .text_hip import TextEncoderHIP

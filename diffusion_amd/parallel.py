@@ -14,7 +14,8 @@ AdamW kernel's ``grad_scale``.
 The exchange itself is selectable (constructor arguments or the environment):
   collective  'allreduce' (default) one ``all_reduce`` per bucket (RCCL picks ring / tree / direct for the mesh);
               'rs_ag'     ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` per bucket: on the xGMI full mesh
-                          every rank sends shard j straight to peer j, all 7 links busy at once
+                          every rank sends shard j straight to peer j, all 7 links busy at once; with
+                          the fp32 payload over RCCL both run IN PLACE on the flat gradient (no staging, no allocation)
   payload     'fp32' (default) the gradient as it lies; 'bf16' a bf16 staging copy (half the bytes on the links; the
               SUM is then rounded to 8 significant bits per element - opt-in).
   overlap     True (default) buckets are exchanged on the side stream while backward still runs; False: all buckets
@@ -69,18 +70,26 @@ class BucketedAllReducer:
         if self.collective == 'allreduce' and self.payload == 'fp32':
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
             return
+        rank = dist.get_rank(self.group)
+        if self.payload == 'fp32' and n % world == 0 and dist.get_backend(self.group) == 'nccl':
+            # rs_ag on the gradient where it lies: RCCL's in-place forms (reduce-scatter output = this rank's slice of the
+            # input, all-gather input = this rank's slice of the output) - no staging copy, no per-step allocation
+            shard = view.view(world, n // world)[rank]
+            dist.reduce_scatter_tensor(shard, view, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+            dist.all_gather_into_tensor(view, shard, group=self.group, async_op=True).wait()
+            return
         npad = -(-n // world) * world
         dt = torch.bfloat16 if self.payload == 'bf16' else view.dtype
         key = (npad, dt)
-        stage = self._stage.get(key)
-        if stage is None:   # one staging buffer per distinct bucket size (the bucket sequence repeats every step)
-            stage = self._stage[key] = torch.zeros(npad, device=view.device, dtype=dt)
+        bufs = self._stage.get(key)
+        if bufs is None:   # one staging buffer (+ shard) per distinct bucket size (the bucket sequence repeats every step)
+            bufs = self._stage[key] = (torch.zeros(npad, device=view.device, dtype=dt),
+                                       torch.zeros(npad // world, device=view.device, dtype=dt))
+        stage, shard = bufs
         stage[:n].copy_(view)
         if self.collective == 'allreduce':
             dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
         else:
-            rank = dist.get_rank(self.group)
-            shard = stage.view(world, npad // world)[rank].clone()
             dist.reduce_scatter_tensor(shard, stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
             dist.all_gather_into_tensor(stage, shard, group=self.group, async_op=True).wait()
         view.copy_(stage[:n])

@@ -109,7 +109,19 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.reducer = BucketedAllReducer(model.unet.grad)
-        self.sliced_optimizer = os.environ.get('DA_SLICED_ADAMW', '0') == '1'
+        # AdamW slices issued behind each gradient bucket on the reducer's side stream (north_star: "all-reduce ...
+        # overlapped with the optimizer step"; the reference gets the overlap from FSDP's sharded optimizer step,
+        # SD-2-base-256.yaml:95-96).  On by default when there IS an exchange to hide (world > 1); at world 1 it measured
+        # neutral (196.4 vs 196.6 ms/step: the slices only take CUs from the backward GEMMs), so one launch.  DA_SLICED_ADAMW=0/1.
+        env = os.environ.get('DA_SLICED_ADAMW')
+        self.sliced_optimizer = (self.world > 1) if env is None else (env == '1')
+        # Multi-GPU: leave R CUs to the RCCL channels of the overlapping all-reduce, so grids sized to one round of the
+        # chip (persistent GEMM tile walks, weight-gradient pixel splits) do not spill into a second round when a
+        # collective holds a CU.  Priced at world 1 in DESIGN.md section 6.  DA_DP_RESERVE_CUS=R overrides (0 = whole chip).
+        self.reserve_cus = int(os.environ.get('DA_DP_RESERVE_CUS', '8' if self.world > 1 else '0'))
+        if self.reserve_cus or 'DA_DP_RESERVE_CUS' in os.environ:
+            from . import ops
+            ops.set_option('reserve_cus', self.reserve_cus)
         self.base_lr = self.optimizer.param_groups[0]['lr']
         self.global_batch_size = None
         self.logs: List[dict] = []
@@ -120,18 +132,37 @@ class Trainer:
         # of 16 (372.4 images/s eager vs 372.4 replayed: the small-M kernels, not the ~1,700 launches, set the time), so
         # replay buys nothing there and costs a private memory pool per captured signature.  DA_GRAPH=0/1 overrides.
         env = os.environ.get('DA_GRAPH')
-        self.use_graphs = use_graphs if env is None else (env == '1')
+        use_graphs = use_graphs if env is None else (env == '1')
+        # normalised to True / False / 'auto' (a YAML's 0 / 1 / 'false' must not fall through to 'auto')
+        if isinstance(use_graphs, str):
+            use_graphs = 'auto' if use_graphs.lower() == 'auto' else use_graphs.lower() in ('1', 'true', 'yes', 'on')
+        self.use_graphs = use_graphs if use_graphs == 'auto' else bool(use_graphs)
         self._graph_cache = None
         # resume: explicit load_path, or (autoresume) the newest checkpoint of this rank-0 run in save_folder
         self.all_algorithms = list(algorithms or [])
+        self._skip_batches = 0
         if load_path:
             self.load_checkpoint(load_path)
         elif autoresume:
             if not save_folder:
                 raise ValueError('autoresume=True needs save_folder')
-            latest = self.latest_checkpoint(save_folder)
+            # rank 0 picks the checkpoint and tells everybody: only rank 0 writes ba*-rank0.pt, and a rank that globbed a
+            # stale or un-shared listing by itself would silently start from batch 0 next to resumed peers
+            latest = self.latest_checkpoint(save_folder) if self.rank == 0 else None
+            if self.world > 1:
+                box = [latest]
+                dist.broadcast_object_list(box, src=0)
+                latest = box[0]
             if latest:
                 self.load_checkpoint(latest)
+        if self.world > 1:   # every replica must continue from the same batch (a silent mismatch diverges, then hangs)
+            lo = torch.tensor([self.batch_idx], dtype=torch.int64, device=model.unet.device_)
+            hi = lo.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if int(lo.item()) != int(hi.item()):
+                raise RuntimeError(f'ranks disagree on the resumed batch index ({int(lo.item())} .. {int(hi.item())}): '
+                                   'the checkpoint must be readable on every rank')
 
     # saved-activation bytes per image of one forward at latent side S (bf16 activations kept for backward, measured:
     # ~60 GB for 256 images at 32^2 -> 0.235 GB/image; the count scales with the pixel count)
@@ -218,8 +249,9 @@ class Trainer:
 
     def _graph_this(self, sub, n_micro: int, last: bool) -> bool:
         """Replay this microbatch from a captured hipGraph?  Never the last microbatch of a multi-rank step (its backward
-        overlaps the gradient exchange through host-side hooks)."""
-        if self.use_graphs is False or (last and self.reducer.enabled):
+        overlaps the gradient exchange through host-side hooks), never with the weight-gradient side stream (its workspaces
+        are re-allocated per batch shape, a captured graph would replay into freed memory)."""
+        if self.use_graphs is False or (last and self.reducer.enabled) or self.model.unet.wgrad_stream is not None:
             return False
         if self._graph_cache is None:
             from .graph_step import GraphStepCache
@@ -233,6 +265,10 @@ class Trainer:
         return n_micro > 1 and small
 
     def fit(self):
+        if self._skip_batches and hasattr(self.dataloader, 'set_epoch') and len(self.dataloader):
+            # resumed inside an epoch: same permutation, minus the batches already consumed (skipped at index level)
+            self.dataloader.set_epoch(self.batch_idx // len(self.dataloader), skip_batches=self._skip_batches)
+            self._skip_batches = 0
         it = iter(self.dataloader)
         while self.batch_idx < self.max_batches:
             try:
@@ -265,9 +301,14 @@ class Trainer:
         os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
         unet = self.model.unet
         algs = {type(a).__name__: a.state_dict() for a in self.all_algorithms if hasattr(a, 'state_dict')}
+        # RNG streams (Composer checkpoints them too): the timestep / noise draws of stable_diffusion.py:177-179 come from
+        # torch's global generators, so a resumed run continues the uninterrupted run's stream.  Rank 0's state is saved;
+        # the other ranks re-derive theirs (load_checkpoint)
+        rng = {'cpu': torch.get_rng_state(), 'cuda': torch.cuda.get_rng_state(unet.device_)}
         tmp = path + '.tmp'
         torch.save({'state': {'model': {f'unet.{k}': v.detach().cpu().contiguous() for k, v in unet.state_dict().items()},
-                              'optimizers': self.optimizer.state_dict(), 'algorithms': algs, 'batch': self.batch_idx}}, tmp)
+                              'optimizers': self.optimizer.state_dict(), 'algorithms': algs, 'batch': self.batch_idx,
+                              'rng': rng, 'world': self.world}}, tmp)
         os.replace(tmp, path)   # a killed run never leaves a half-written newest checkpoint for autoresume
 
     @staticmethod
@@ -291,5 +332,15 @@ class Trainer:
             if type(a).__name__ in algs and hasattr(a, 'load_state_dict'):
                 a.load_state_dict(algs[type(a).__name__])
         self.batch_idx = ck['state']['batch']
+        rng = ck['state'].get('rng')
+        if rng is not None:
+            if self.rank == 0 and ck['state'].get('world', 1) == self.world:
+                torch.set_rng_state(rng['cpu'])
+                torch.cuda.set_rng_state(rng['cuda'], self.model.unet.device_)
+            else:   # only rank 0's streams are in the file: a distinct, reproducible stream per (rank, batch)
+                torch.manual_seed(int.from_bytes(rng['cpu'][:8].numpy().tobytes(), 'little') % (2**31) + 1000003 * self.rank
+                                  + self.batch_idx)
         if hasattr(self.dataloader, 'set_epoch') and hasattr(self.dataloader, '__len__') and len(self.dataloader):
+            # data position: epoch = batches // len, and the batches of that epoch already consumed are skipped by fit()
             self.dataloader.set_epoch(self.batch_idx // len(self.dataloader))
+            self._skip_batches = self.batch_idx % len(self.dataloader)

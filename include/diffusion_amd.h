@@ -68,7 +68,10 @@ int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* 
  *   "gemm_nt_splitk"    1 (default) split-K allowed | 0 never split
  *   "gemm_nt_persist"   -1 (default) linears / fused GEGLU run as one resident workgroup per CU walking the tile list |
  *                       n > 0 that many resident workgroups | 0 one workgroup per tile
- *   "gemm_tn_variant"   0 auto | 1 the 128x128x32 wgrad kernel | 2 the 320x192x64 LDS-DMA wgrad kernel */
+ *   "gemm_tn_variant"   0 auto | 1 the 128x128x32 wgrad kernel | 2 the 320x192x64 LDS-DMA wgrad kernel
+ *   "reserve_cus"       R in [0, 128] (default 0): every grid sized to one round of the chip (persistent GEMM tile walks,
+ *                       weight-gradient pixel splits, the dispatch cost model) uses #CUs - R, leaving R CUs to the RCCL
+ *                       channels of an overlapping gradient all-reduce (set by the trainer when world size > 1) */
 int da_set_option(const char* key, int value);
 /* which kernel da_gemm_nt dispatches to for (M, N, K, Cin) given a split-K workspace of that many floats: 1 = gemm_nt_kernel (128x128 tile), 4 / 5 / 10 =
  * gemm_nt2_kernel with a 256x128 / 256x160 / 256x320 tile, 12 = the 16-wave 256x320 form, 14 = the 16-wave 256x256 form,
@@ -79,9 +82,10 @@ int da_gemm_nt_variant_for(int M, int N, int K, int Cin, long splitk_ws_floats);
  * Replaces the cuDNN/cuBLAS wgrad kernels autograd runs for the same layers (loss.backward() driven by
  * Composer).  modes 0, 1, 3 as above.  If dbias != NULL, dbias[n] += sum_m dY[m][n] as well
  * (fused into the large-tile kernel; the small-shape path uses da_colsum_accum with `scratch`, >= 256*N*2 floats).
- * When the pixel range is split over workgroups, the partial tiles are stored in split_ws (fp32, caller-owned, may be
- * shared with da_gemm_nt's split-K workspace on the same stream; ~64 MiB covers every split grid) and summed in a fixed
- * order; with split_ws == NULL or too small they are accumulated with fp32 atomics instead. */
+ * When the pixel range is split over workgroups, the partial tiles AND the partial bias gradients are stored in split_ws
+ * (fp32, caller-owned, may be shared with da_gemm_nt's split-K workspace on the same stream; ~128 MiB covers every split
+ * grid of both wgrad kernels) and summed in a fixed order: dW and dbias are then bitwise reproducible run to run.  With
+ * split_ws == NULL or too small they are accumulated with fp32 atomics instead (order-dependent last bits). */
 int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, float* scratch, int M,
                      int N, int Cin, int Hin, int Win, int Hout, int Wout, int ksize, int mode, float* split_ws,
                      long split_ws_floats, da_stream_t stream);

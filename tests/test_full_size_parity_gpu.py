@@ -11,10 +11,11 @@ tests/golden/make_golden_full.py): the prediction, the loss, the L2 norm of ever
 and row slices of 47 gradients covering each kernel class at each resolution level.  If this machine's seeded RNG
 streams do not reproduce the fixture's checksums, the oracle is run live instead (slow, same assertions).
 
-Tolerances (north_star: stated bf16 tolerance; BASELINE.json: loss within 1e-3):
-  prediction rel-L2 <= 2e-2 . |loss - oracle| <= 1e-3 . global gradient rel-L2 (over the stored slices) <= 6e-2 .
-  per-slice cosine >= 0.97 on matrices . per-tensor gradient-norm ratio within [0.9, 1.1] on every tensor whose
-  oracle norm is not negligible (bf16 activations + weights, fp32 accumulation)."""
+Tolerances (north_star: stated bf16 tolerance; BASELINE.json: loss within 1e-3) are the TOL table below: every bound is
+at most twice the margin measured on MI355X (profiles/r03_parity_margins.json, written by this file when
+DA_PARITY_MARGINS=<path> is set: per case the prediction rel-L2, the loss delta, the worst per-tensor gradient-norm ratio
+and its tensor, the whole-gradient norm ratio, the worst per-slice cosine and its tensor, the global rel-L2 over the
+stored slices).  bf16 activations + weights, fp32 accumulation."""
 import math
 import os
 import sys
@@ -27,6 +28,29 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 sys.path.insert(0, GOLD)
+
+
+# bound = min(2 x measured margin, the previous round's bound); measured values: profiles/r03_parity_margins.json
+TOL = {
+    'pred_rel': 2e-2,          # prediction rel-L2
+    'loss_abs': 1e-3,          # |loss - oracle|  (BASELINE.json: within 1e-3)
+    'norm_lo': 0.9, 'norm_hi': 1.1,   # per-tensor gradient-norm ratio
+    'total_lo': 0.97, 'total_hi': 1.03,  # whole-gradient norm ratio
+    'slice_cos': 0.97,         # per-slice cosine (matrices)
+    'slice_rel': 6e-2,         # global rel-L2 over the stored gradient slices
+}
+MARGINS = {}
+
+
+def _record(case, **kv):
+    """Keep the measured margins of a case; with DA_PARITY_MARGINS=<path> they are (re)written there as JSON."""
+    MARGINS.setdefault(case, {}).update(kv)
+    path = os.environ.get('DA_PARITY_MARGINS')
+    if path:
+        import json
+        os.makedirs(os.path.dirname(os.path.abspath(path)) or '.', exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump({'tolerances': TOL, 'measured': MARGINS}, f, indent=1, sort_keys=True)
 
 
 def _rel(a, b):
@@ -58,7 +82,7 @@ def _oracle_live(O, sd, cfg_name, latents, t, ctx, noise, slices):
     return fx
 
 
-def _check_step(O, sd, model, dev, cfg_name, latents, ctx, noise, t, fx, slices):
+def _check_step(O, sd, model, dev, cfg_name, latents, ctx, noise, t, fx, slices, case):
     v_pred = getattr(O.UNetConfig, cfg_name)().prediction_type == 'v_prediction'
     old = model.prediction_type
     model.prediction_type = 'v_prediction' if v_pred else 'epsilon'
@@ -68,11 +92,10 @@ def _check_step(O, sd, model, dev, cfg_name, latents, ctx, noise, t, fx, slices)
         out = model(batch, timesteps=t.to(dev), noise=noise.to(dev))
         pred_ref = torch.from_numpy(fx['pred'])
         e = _rel(out[0].cpu(), pred_ref)
-        assert e < 2e-2, f'prediction rel-L2 {e}'
         if 'target' in fx:
             assert _rel(out[1].cpu(), torch.from_numpy(fx['target'])) < 1e-5
         loss = model.loss(out, batch)
-        assert abs(loss.item() - float(fx['loss'])) < 1e-3, (loss.item(), float(fx['loss']))
+        dl = abs(loss.item() - float(fx['loss']))
         loss.backward()
         torch.cuda.synchronize()
     finally:
@@ -84,13 +107,11 @@ def _check_step(O, sd, model, dev, cfg_name, latents, ctx, noise, t, fx, slices)
     got_norms = np.array([float(params[k].grad.detach().double().norm()) for k in keys])
     big = ref_norms > 1e-3 * ref_norms.max()
     ratio = got_norms[big] / ref_norms[big]
-    worst = np.argmax(np.abs(ratio - 1.0))
-    assert np.all((ratio > 0.9) & (ratio < 1.1)), (np.array(keys)[big][worst], ratio[worst])
+    worst = int(np.argmax(np.abs(ratio - 1.0)))
     tot = math.sqrt((got_norms**2).sum() / (ref_norms**2).sum())
-    assert 0.97 < tot < 1.03, tot
     # (2) the stored gradient slices
     num = den = 0.0
-    bad = []
+    worst_cos = (None, 1.0)
     for k, rows in slices:
         r = torch.from_numpy(fx['grad.' + k])
         g = params[k].grad.detach().float().cpu()
@@ -100,10 +121,20 @@ def _check_step(O, sd, model, dev, cfg_name, latents, ctx, noise, t, fx, slices)
         den += (r**2).sum().item()
         if r.dim() >= 2 and r.norm() > 0:
             c = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item()
-            if c < 0.97:
-                bad.append((k, c))
-    assert not bad, bad
-    assert math.sqrt(num / den) < 6e-2, math.sqrt(num / den)
+            if c < worst_cos[1]:
+                worst_cos = (k, c)
+    srel = math.sqrt(num / den)
+    _record(case, pred_rel_l2=e, loss_abs_delta=dl, loss=float(loss.item()), loss_oracle=float(fx['loss']),
+            worst_norm_ratio=float(ratio[worst]), worst_norm_tensor=str(np.array(keys)[big][worst]),
+            norm_ratio_min=float(ratio.min()), norm_ratio_max=float(ratio.max()), total_norm_ratio=tot,
+            worst_slice_cosine=worst_cos[1], worst_slice_tensor=worst_cos[0], slices_rel_l2=srel,
+            tensors_compared=int(big.sum()))
+    assert e < TOL['pred_rel'], f'prediction rel-L2 {e}'
+    assert dl < TOL['loss_abs'], (loss.item(), float(fx['loss']))
+    assert np.all((ratio > TOL['norm_lo']) & (ratio < TOL['norm_hi'])), (np.array(keys)[big][worst], ratio[worst])
+    assert TOL['total_lo'] < tot < TOL['total_hi'], tot
+    assert worst_cos[1] >= TOL['slice_cos'], worst_cos
+    assert srel < TOL['slice_rel'], srel
 
 
 @pytest.mark.parametrize('case', ['s32', 's64', 's96'])
@@ -119,7 +150,7 @@ def test_full_width_train_step_vs_oracle_fixture(full, dev, case):
         np.array_equal(fx['t'], t.numpy())
     if not same_streams:  # this machine's torch RNG does not reproduce the fixture's inputs: run the oracle here
         fx = _oracle_live(O, sd, cfg_name, latents, t, ctx, noise, G.SLICES)
-    _check_step(O, sd, model, dev, cfg_name, latents, ctx, noise, t, fx, G.SLICES)
+    _check_step(O, sd, model, dev, cfg_name, latents, ctx, noise, t, fx, G.SLICES, case)
 
 
 def test_full_pipeline_256px_unet_half_vs_oracle(full, dev):
@@ -160,18 +191,55 @@ def _full_pipeline_body(O, sd, model, dev, G):
     torch.manual_seed(3)
     model.unet.zero_grad()
     out = model(batch, timesteps=t.to(dev), noise=noise.to(dev))
-    assert _rel(out[0].cpu(), torch.from_numpy(fx['pred'])) < 2e-2
+    e = _rel(out[0].cpu(), torch.from_numpy(fx['pred']))
     loss = model.loss(out, batch)
-    assert abs(loss.item() - float(fx['loss'])) < 1e-3, (loss.item(), float(fx['loss']))
+    dl = abs(loss.item() - float(fx['loss']))
     loss.backward()
     torch.cuda.synchronize()
     params = dict(model.unet.named_parameters())
     num = den = 0.0
+    worst_cos = (None, 1.0)
     for k, rows in G.SLICES:
         r = torch.from_numpy(fx['grad.' + k])
         gg = params[k].grad.detach().float().cpu()
         gg = gg if rows is None else gg[:rows]
         num += ((gg - r)**2).sum().item()
         den += (r**2).sum().item()
-    assert math.sqrt(num / den) < 6e-2, math.sqrt(num / den)
+        if r.dim() >= 2 and r.norm() > 0:
+            c = torch.nn.functional.cosine_similarity(gg.flatten(), r.flatten(), dim=0).item()
+            if c < worst_cos[1]:
+                worst_cos = (k, c)
+    srel = math.sqrt(num / den)
+    _record('cfg3_256px_online_encode', pred_rel_l2=e, loss_abs_delta=dl, loss=float(loss.item()),
+            loss_oracle=float(fx['loss']), worst_slice_cosine=worst_cos[1], worst_slice_tensor=worst_cos[0],
+            slices_rel_l2=srel)
+    assert e < TOL['pred_rel'], e
+    assert dl < TOL['loss_abs'], (loss.item(), float(fx['loss']))
+    assert worst_cos[1] >= TOL['slice_cos'], worst_cos
+    assert srel < TOL['slice_rel'], srel
     assert all(not p.requires_grad for p in model.vae.parameters())
+
+
+def test_two_identical_steps_give_bitwise_equal_gradients(full, dev):
+    """Every reduction on the path sums in a fixed order (weight / bias gradient slabs, norm-affine column sums, split-K,
+    attention dQ by its own kernel - no fp32 atomics anywhere when the workspaces are passed, as UNetHIP does): two runs
+    of the same step must produce the same 865.9 M gradient words bit for bit, and the same loss and prediction."""
+    import make_golden_full as G
+    O, sd, model = full
+    _, cfg_name, B, S, _, iseed = G.CASES['s32']
+    cfg = getattr(O.UNetConfig, cfg_name)()
+    latents, ctx, noise, t = G.inputs(B, S, cfg.cross_attention_dim, iseed)
+    batch = {'image_latents': latents.to(dev), 'caption_latents': ctx.to(dev)}
+    runs = []
+    for _ in range(2):
+        model.unet.zero_grad()
+        out = model(batch, timesteps=t.to(dev), noise=noise.to(dev))
+        loss = model.loss(out, batch)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((model.unet.grad.clone(), out[0].clone(), float(loss.item())))
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][2] == runs[1][2]
+    diff = (runs[0][0] != runs[1][0])
+    assert not bool(diff.any()), f'{int(diff.sum())} gradient words differ between two identical steps'
+    _record('determinism_s32_b2', gradient_words=int(runs[0][0].numel()), differing_words=int(diff.sum()))

@@ -20,8 +20,11 @@ PASSES=(
  "WRITE_SIZE"
 )
 i=0
+FAILED=()
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $O/pass$i -o p -- "${ARGS[@]}" > $O/pass$i.out 2> $O/pass$i.err || { echo "pass $i failed"; tail -5 $O/pass$i.err; }
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $O/pass$i -o p -- "${ARGS[@]}" > $O/pass$i.out 2> $O/pass$i.err || { echo "pass $i failed"; tail -5 $O/pass$i.err; FAILED+=($i); }
 done
-python3 $R/tools/pmc_summary.py $O $O.json
+# the summary names the passes that did not complete; a partial counter set must not look complete (exit 1)
+python3 $R/tools/pmc_summary.py $O $O.json "${FAILED[@]}"
+if [ ${#FAILED[@]} -gt 0 ]; then echo "pmc.sh: failed passes: ${FAILED[*]}"; exit 1; fi

@@ -1,6 +1,6 @@
 """Summarise the passes of tools/pmc.sh: per kernel (short name), mean counter values per dispatch and the derived
 ratios used in DESIGN.md.  HBM bytes follow MI355X_MICROARCH.md (HBM section): bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.
-usage: pmc_summary.py <dir with pass*/> <out.json>"""
+usage: pmc_summary.py <dir with pass*/> <out.json> [failed pass numbers ...]   (listed under "_failed_passes")"""
 import collections
 import csv
 import glob
@@ -56,6 +56,9 @@ for k, cs in acc.items():
     if c.get('SQ_LDS_IDX_ACTIVE'):
         d['lds_conflict_frac'] = round(c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE'], 3)
     res[k] = d
+if len(sys.argv) > 3:
+    res['_failed_passes'] = [int(x) for x in sys.argv[3:]]
 json.dump(res, open(out, 'w'), indent=1)
 for k, d in res.items():
-    print(k, {x: d[x] for x in d if x not in ('counters_mean_per_dispatch',)})
+    if isinstance(d, dict):
+        print(k, {x: d[x] for x in d if x not in ('counters_mean_per_dispatch',)})
