@@ -12,7 +12,7 @@
 //   cross-workgroup sum; P and dS accumulators are again the B operands of dV^T += dO^T.P and
 //   dK^T += Q^T.dS.  dQ is produced by the separate query-major kernel (recomputing S and dP) instead
 //   of fp32 atomics, which keeps all three gradients bitwise reproducible.
-// Row-read operands (K, V, Q, dO by rows) use a 128-B-row image with the 16-B chunk XOR ((row>>1)&7).
+// Every operand tile is ONE 128-B-row LDS image whose chunk swizzle serves row reads and transposed reads alike (swz_key).
 // Softmax is computed in the exp2 domain: p = exp2(s*scale*log2e - L2), L2 = m + log2(sum) saved per row.
 #include <type_traits>
 
@@ -31,14 +31,21 @@ struct AttnParams {
   float scale;  // softmax scale
 };
 
-// Transposed-read image: [rows][64 bf16] with unpadded 128-B rows; the 64-B half of a row is XOR-ed with bit 1 of the
-// row index.  A 32-lane half of ds_read_b64_tr_b16 touches 64 contiguous bytes of 4 consecutive rows: rows r, r+1 sit in
-// different 128-B halves of the 256-B bank span and rows r, r+2 in different 64-B halves of those, so the reads are
-// conflict-free without the 192-B padded rows used before (which kept the dQ kernel at two workgroups per CU).
+// ONE LDS image per operand tile, [rows][64 bf16] with unpadded 128-B rows, serves both kinds of read: the 16-B chunk index of
+// row r is XOR-ed with key(r) = (bit 1 of r) << 2 | (bits 2-3 of r).
+//  * ds_read_b128 row fragments (16 rows x one chunk per lane group {0-3,12-15,20-27} / {4-11,16-19,28-31}): the row parity
+//    picks the 128-B half of the 256-B bank span and key(r) takes all 8 values over the rows of a group, so the 16 lanes hit
+//    16 distinct 16-B slots;
+//  * ds_read_b64_tr_b16 (a 32-lane half touches one 64-B half of 4 consecutive rows r0..r0+3, r0 % 4 == 0): bits 2-3 of r are
+//    constant over them (a permutation of the chunks inside the 64 bytes), bit 1 flips the 64-B half and bit 0 the 128-B
+//    half - four distinct 64-B quarters of the bank span.
+// Until round 3 the row image (key (r>>1)&7) and the transposed-read image (key bit 1 only) were separate copies of the same
+// tile: twice the LDS-DMA requests (the per-step request block is wave time with the matrix pipe idle) and twice the LDS.
 constexpr int TR_LD = 128;
-DEVINL int tr_off(int row, int bytecol) { return row * TR_LD + (bytecol ^ (((row >> 1) & 1) << 6)); }
+DEVINL int swz_key(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+DEVINL int tr_off(int row, int bytecol) { return row * TR_LD + (bytecol ^ (swz_key(row) << 4)); }
 
-DEVINL int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+DEVINL int swz128(int row, int chunk) { return row * 128 + ((chunk ^ swz_key(row)) << 4); }
 
 // A operand of the 32x32x16 MFMA for (rows = columns col0..col0+31 of a transposed-read image, k = 16 image rows
 // starting at row0) in the accumulator-as-operand k order: element j <-> image row row0 + 8*(j>>2) + 4*(lane>>5) + (j&3).
@@ -147,8 +154,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   // K / V tiles (64 keys) reach LDS by DMA, one tile ahead into the stage the previous step released: K as the row image,
   // V as the transposed-read image.  Wave w fills rows 8w..8w+7 and 32+8w..32+8w+7 of both.
   const int drow = wave * 8 + (lane >> 3), pc = lane & 7;
-  const int lc_row = (pc ^ ((drow >> 1) & 7)) * 8;
-  const int lc_tr = (pc ^ (((drow >> 1) & 1) << 2)) * 8;
+  const int lc = (pc ^ swz_key(drow)) * 8;  // source element offset behind physical chunk pc (rows drow, drow + 32: same key)
   const bf16* kp = p.K + ((long)b * p.Nk + drow) * p.ldk + hd * 64;
   const bf16* vp = p.V + ((long)b * p.Nk + drow) * p.ldv + hd * 64;
   const char* zero = reinterpret_cast<const char*>(g_attn_zero);
@@ -157,8 +163,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool ok = t * 64 + drow + 32 * i < p.Nk;
-      dma16(ok ? (const void*)(kp + 32 * i * p.ldk + lc_row) : (const void*)zero, S + i * 4096);
-      dma16(ok ? (const void*)(vp + 32 * i * p.ldv + lc_tr) : (const void*)zero, S + 8192 + i * 4096);
+      dma16(ok ? (const void*)(kp + 32 * i * p.ldk + lc) : (const void*)zero, S + i * 4096);
+      dma16(ok ? (const void*)(vp + 32 * i * p.ldv + lc) : (const void*)zero, S + 8192 + i * 4096);
     }
     kp += 64 * p.ldk;
     vp += 64 * p.ldv;
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------
 // backward, query-major: dQ (and delta = rowsum(dO*O), stored for the dK/dV kernel).  Same pipeline as forward.
 // ------------------------------------------------------------------------------------------------
-constexpr int DQ_STAGE = 2 * 64 * 128 + 64 * TR_LD;
+constexpr int DQ_STAGE = 2 * 64 * 128;  // K and V images (K is read by rows for S and transposed for dQ)
 
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * DQ_STAGE, dynamic: see attn_bwd_dkv_kernel
@@ -310,11 +316,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 
   const int nt = (p.Nk + 63) / 64;
   // K / V tiles (64 keys) reach LDS by DMA, one tile ahead into the stage the previous step released: no staging
-  // registers, no ds_write pass.  Wave w fills rows 8w..8w+7 and 32+8w..32+8w+7 of the three images (K and V row images,
-  // K transposed-read image).
+  // registers, no ds_write pass.  Wave w fills rows 8w..8w+7 and 32+8w..32+8w+7 of the two images.
   const int drow = wave * 8 + (lane >> 3), pc = lane & 7;
-  const int lc_row = (pc ^ ((drow >> 1) & 7)) * 8;
-  const int lc_tr = (pc ^ (((drow >> 1) & 1) << 2)) * 8;
+  const int lc = (pc ^ swz_key(drow)) * 8;
   const bf16* kp = p.K + ((long)b * p.Nk + drow) * p.ldk + hd * 64;
   const bf16* vp = p.V + ((long)b * p.Nk + drow) * p.ldv + hd * 64;
   const char* zero = reinterpret_cast<const char*>(g_attn_zero);
@@ -323,11 +327,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool ok = t * 64 + drow + 32 * i < p.Nk;
-      const bf16* kr = kp + 32 * i * p.ldk;
-      const bf16* vr = vp + 32 * i * p.ldv;
-      dma16(ok ? (const void*)(kr + lc_row) : (const void*)zero, S + i * 4096);
-      dma16(ok ? (const void*)(vr + lc_row) : (const void*)zero, S + 8192 + i * 4096);
-      dma16(ok ? (const void*)(kr + lc_tr) : (const void*)zero, S + 16384 + i * 4096);
+      dma16(ok ? (const void*)(kp + 32 * i * p.ldk + lc) : (const void*)zero, S + i * 4096);
+      dma16(ok ? (const void*)(vp + 32 * i * p.ldv + lc) : (const void*)zero, S + 8192 + i * 4096);
     }
     kp += 64 * p.ldk;
     vp += 64 * p.ldv;
@@ -345,14 +346,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
     if (t + 1 < nt) dma(t + 1, (t + 1) & 1);
     const char* Ks = smem + (t & 1) * DQ_STAGE;
     const char* Vs = Ks + 64 * 128;
-    const char* Kt = Ks + 2 * 64 * 128;
+    const char* Kt = Ks;  // the same image, read transposed
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int kb = half * 32;
       if (TAIL && t * 64 + kb >= p.Nk) break;
+      // the row constant -delta is the START value of the dP accumulators: dP - delta leaves the MFMA chain ready
       f32x16 s, dp;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = -delta; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + swz128(kb + r, 2 * ks + h));
@@ -369,11 +371,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
         tr_frag_issue(kto, kb + 16 * s2, 32, lane, tk1[s2][0], tk1[s2][1]);
       }
       {
-        const f32x2 sc2 = {p.sc, p.sc}, nl2 = {nL2q, nL2q}, nde2 = {-delta, -delta};
+        const f32x2 sc2 = {p.sc, p.sc}, nl2 = {nL2q, nL2q};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const f32x2 pv = exp2_2(__builtin_elementwise_fma(pair(s, i), sc2, nl2));
-          set_pair(s, i, pv * (pair(dp, i) + nde2));
+          set_pair(s, i, pv * pair(dp, i));
         }
       }
       if constexpr (TAIL) {
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 // backward, key-major: dK, dV.  Workgroup = 128 keys (4 waves x 32), sweeps all queries in 32-row tiles
 // (three LDS stages filled by DMA two tiles ahead, one barrier per tile).
 // ------------------------------------------------------------------------------------------------
-constexpr int KV_STAGE = 4 * 32 * 128 + 2 * 32 * 4;  // Q, dO row images; Q, dO transposed-read images; L2, delta
+constexpr int KV_STAGE = 2 * 32 * 128 + 2 * 32 * 4;  // Q, dO images (read by rows and transposed); L2, delta
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
   // dynamic LDS on purpose: against a static __shared__ array the compiler treats every LDS-DMA as a possibly
@@ -442,11 +444,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
   // Q / dO tiles (32 queries) reach LDS by DMA, three stages, issued TWO tiles ahead: a 32-query step lasts about one
   // global-load latency, and with the register-staged prefetch consumed at the end of the same step the kernel spent
   // 55 % of its wave-cycles waiting (skipping the loads made it 31 % faster).  Wave w fills rows 8w..8w+7 of the
-  // four images (row / transposed-read image of Q and of dO); wave 0 also fetches the 32 L2 and 32 delta values.
+  // two images (Q, dO); wave 0 also fetches the 32 L2 and 32 delta values.
   const int nt = (p.Nq + 31) / 32;
   const int drow = wave * 8 + (lane >> 3), pc = lane & 7;
-  const int lc_row = (pc ^ ((drow >> 1) & 7)) * 8;         // source element offset behind physical chunk pc: swz128
-  const int lc_tr = (pc ^ (((drow >> 1) & 1) << 2)) * 8;   //   ... and the transposed-read image (tr_off)
+  const int lc = (pc ^ swz_key(drow)) * 8;                 // source element offset behind physical chunk pc
   const bf16* qp = p.Q + ((long)b * p.Nq + drow) * p.ldq + hd * 64;
   const bf16* dop = p.dO + ((long)b * p.Nq + drow) * p.lddo + hd * 64;
   const float* statp = (lane < 32 ? p.L2 : p.Delta) + ((long)b * p.H + hd) * p.Nq + (lane & 31);
@@ -454,23 +455,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
   auto dma = [&](int t, int st) {  // tiles are requested in order: the pointers advance by one tile per call
     char* S = smem + st * KV_STAGE + wave * 1024;
     const bool ok = t * 32 + drow < p.Nq;
-    dma16(ok ? (const void*)(qp + lc_row) : (const void*)zero, S);
-    dma16(ok ? (const void*)(dop + lc_row) : (const void*)zero, S + 4096);
-    dma16(ok ? (const void*)(qp + lc_tr) : (const void*)zero, S + 2 * 4096);
-    dma16(ok ? (const void*)(dop + lc_tr) : (const void*)zero, S + 3 * 4096);
+    dma16(ok ? (const void*)(qp + lc) : (const void*)zero, S);
+    dma16(ok ? (const void*)(dop + lc) : (const void*)zero, S + 4096);
     if (wave == 0) {
       const bool ok2 = t * 32 + (lane & 31) < p.Nq;
-      dma4(ok2 ? (const void*)statp : (const void*)zero, smem + st * KV_STAGE + 4 * 4096);
+      dma4(ok2 ? (const void*)statp : (const void*)zero, smem + st * KV_STAGE + 2 * 4096);
     }
     qp += 32 * p.ldq;
     dop += 32 * p.lddo;
     statp += 32;
   };
-  // wait until at most the DMAs of the newest requested tile are outstanding (4 per wave, 5 on wave 0), then barrier
+  // wait until at most the DMAs of the newest requested tile are outstanding (2 per wave, 3 on wave 0), then barrier
   auto sync_tiles = [&](bool newest_in_flight) {
     if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -483,13 +482,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
     if (t + 2 < nt) dma(t + 2, (t + 2) % 3);  // its stage was last read in step t-1, released by that step's barrier
     const char* Qs = smem + (t % 3) * KV_STAGE;
     const char* Os = Qs + 4096;
-    const char* Qt = Qs + 2 * 4096;
-    const char* Ot = Qs + 3 * 4096;
-    const float* Ls = reinterpret_cast<const float*>(Qs + 4 * 4096);
+    const char* Qt = Qs;  // the same images, read transposed
+    const char* Ot = Os;
+    const float* Ls = reinterpret_cast<const float*>(Qs + 2 * 4096);
     const float* Ds = Ls + 32;
+    // the row constants -delta[q] are the START values of the dP accumulators (row q of register i: acc_row)
     f32x16 s, dp;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+    for (int rg = 0; rg < 4; ++rg) {
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + 8 * rg + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[4 * rg + e] = 0.f; dp[4 * rg + e] = -d4[e]; }
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + swz128(r, 2 * ks + h));
@@ -512,17 +516,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + 8 * rg + 4 * h);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + 8 * rg + 4 * h);
       const f32x2 sc2 = {p.sc, p.sc};
 #pragma unroll
       for (int e2 = 0; e2 < 2; ++e2) {
         const int i = rg * 2 + e2;  // pair index: accumulator registers 2i, 2i+1 = rows 2*e2, 2*e2+1 of this group
         const f32x2 pv = exp2_2(__builtin_elementwise_fma(pair(s, i), sc2, -f32x2{l4[2 * e2], l4[2 * e2 + 1]}));
         set_pair(pr, i, pv);
-        set_pair(s, i, pv * (pair(dp, i) - f32x2{d4[2 * e2], d4[2 * e2 + 1]}));
+        set_pair(s, i, pv * pair(dp, i));
       }
     }
-    // rows beyond Nq in the last tile: Q = dO = 0, L2 = delta = 0 -> p = 1, dS = 0, and dO^T.P adds 0.
+    // rows beyond Nq in the last tile: Q = dO = 0, L2 = delta = 0 -> p = 1, dP - delta = 0, dS = 0, and dO^T.P adds 0.
     bf16x8 pf[2] = {pack8(pr, 0), pack8(pr, 1)};
     bf16x8 dsf[2] = {pack8(s, 0), pack8(s, 1)};
     lds_wait_for<0>(to0[0][0], to0[0][1], to1[0][0], to1[0][1], tq0[0][0], tq0[0][1], tq1[0][0], tq1[0][1], to0[1][0],

@@ -332,3 +332,44 @@ def test_mds_reader_on_byte_level_fixture(tmp_path):
     b5 = next(iter(dl5))
     for i, j in enumerate([0, 2, 2, 4, 4]):
         assert torch.equal(b5['image_latents'][i], torch.from_numpy(np.frombuffer(rows[j]['latents_512'], '<f2').copy()).reshape(4, 64, 64))
+
+
+def test_resumable_loader_skips_at_index_level_and_reshuffles_per_epoch():
+    """a resumed run must continue INSIDE its epoch.  The loader's next iterator is epoch e minus its first k
+    batches (no sample loaded for them), the single-process shuffle is a pure function of (seed, epoch)."""
+    from diffusion_amd.datasets.laion.laion import build_streaming_laion_dataloader
+
+    def fingerprints(dl):
+        return [[float(v) for v in b['image_latents'][:, 0, 0, 0]] for b in dl]
+
+    mk = lambda: build_streaming_laion_dataloader(remote=None, local=None, batch_size=4, num_samples=24, shuffle=True,
+                                                  seed=3, num_workers=0)
+    a = mk()
+    assert len(a) == 6
+    e0, e1 = fingerprints(a), fingerprints(a)
+    assert e0 != e1 and sorted(sum(e0, [])) == sorted(sum(e1, []))      # reshuffled, same samples
+    b = mk()
+    b.set_epoch(0, skip_batches=4)
+    assert fingerprints(b) == e0[4:]                                       # rest of epoch 0 ...
+    assert fingerprints(b) == e1                                           # ... then epoch 1 in full
+    c = mk()
+    c.set_epoch(1)
+    assert fingerprints(c) == e1
+
+    class Counting(torch.utils.data.Dataset):
+        def __init__(self):
+            self.loaded = []
+
+        def __len__(self):
+            return 20
+
+        def __getitem__(self, i):
+            self.loaded.append(i)
+            return torch.tensor(i)
+
+    from diffusion_amd.datasets.laion.laion import EpochDataLoader, ResumableBatchSampler
+    ds = Counting()
+    dl = EpochDataLoader(dataset=ds, batch_sampler=ResumableBatchSampler(torch.utils.data.SequentialSampler(ds), 5, True))
+    dl.set_epoch(0, skip_batches=2)
+    got = [x.tolist() for x in dl]
+    assert got == [[10, 11, 12, 13, 14], [15, 16, 17, 18, 19]] and ds.loaded == list(range(10, 20))

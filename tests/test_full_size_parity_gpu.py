@@ -28,29 +28,27 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 sys.path.insert(0, GOLD)
+sys.path.insert(0, os.path.dirname(__file__))
 
 
-# bound = min(2 x measured margin, the previous round's bound); measured values: profiles/r03_parity_margins.json
+# Every bound is <= 2 x the worst margin measured over the four cases on MI355X (profiles/r03_parity_margins.json; the path is
+# deterministic - fixed-order reductions everywhere - so the margins repeat run to run):
+#   measured worst:  prediction rel-L2 1.05e-2 . |loss - oracle| 1.6e-4 . per-tensor gradient-norm ratio 0.9953 .. 1.0039
+#                    whole-gradient norm ratio 1.00026 . per-slice cosine 0.99808 . rel-L2 over the stored slices 4.5e-3
 TOL = {
-    'pred_rel': 2e-2,          # prediction rel-L2
-    'loss_abs': 1e-3,          # |loss - oracle|  (BASELINE.json: within 1e-3)
-    'norm_lo': 0.9, 'norm_hi': 1.1,   # per-tensor gradient-norm ratio
-    'total_lo': 0.97, 'total_hi': 1.03,  # whole-gradient norm ratio
-    'slice_cos': 0.97,         # per-slice cosine (matrices)
-    'slice_rel': 6e-2,         # global rel-L2 over the stored gradient slices
+    'pred_rel': 2e-2,          # prediction rel-L2 (bf16 activations through ~60 layers)
+    'loss_abs': 3e-4,          # |loss - oracle|  (BASELINE.json asks for 1e-3)
+    'norm_lo': 0.991, 'norm_hi': 1.009,   # per-tensor gradient-norm ratio, every tensor with a non-negligible norm
+    'total_lo': 0.9995, 'total_hi': 1.0005,  # whole-gradient norm ratio
+    'slice_cos': 0.9962,       # per-slice cosine (matrices)
+    'slice_rel': 9e-3,         # global rel-L2 over the stored gradient slices
 }
-MARGINS = {}
 
 
 def _record(case, **kv):
-    """Keep the measured margins of a case; with DA_PARITY_MARGINS=<path> they are (re)written there as JSON."""
-    MARGINS.setdefault(case, {}).update(kv)
-    path = os.environ.get('DA_PARITY_MARGINS')
-    if path:
-        import json
-        os.makedirs(os.path.dirname(os.path.abspath(path)) or '.', exist_ok=True)
-        with open(path, 'w') as f:
-            json.dump({'tolerances': TOL, 'measured': MARGINS}, f, indent=1, sort_keys=True)
+    """Keep the measured margins of a case (tests/parity_margins.py; DA_PARITY_MARGINS=<path> writes them as JSON)."""
+    from parity_margins import record
+    record(case, tolerances=TOL, **kv)
 
 
 def _rel(a, b):

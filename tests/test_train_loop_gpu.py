@@ -127,6 +127,42 @@ def test_checkpoint_keeps_ema_and_resume_continues_it(dev, tmp_path):
     assert torch.allclose(tr.optimizer.ema, 0.5 * ema4 + 0.5 * tr.model.unet.master, atol=1e-6)
 
 
+def test_resume_mid_epoch_reproduces_the_uninterrupted_run(dev, tmp_path):
+    """Composer + streaming resume in the MIDDLE of an epoch with the RNG streams restored (SD-2-base-256.yaml:91-94
+    autoresume).  16 shuffled samples, batch 4 (4 batches per epoch): an uninterrupted 6-batch run against 3 batches +
+    checkpoint + a fresh process-like Trainer resumed to 6.  The resumed run must read the same samples (data position:
+    epoch 0 minus its first 3 batches, then epoch 1), draw the same timesteps / noise (RNG state in the checkpoint), and -
+    every reduction on the path being fixed-order - land on the same weights bit for bit."""
+    from diffusion_amd import hydra_lite as h
+    from diffusion_amd.train import train
+    path = os.path.join(ROOT, 'yamls', 'hydra-yamls', 'SD-2-base-256.yaml')
+
+    def cfg(folder, *extra):
+        return h.load_config(path, ['batch_size=4', 'model.model_name=tiny', 'trainer.device_train_microbatch_size=4',
+                                    'dataset.train_dataset.num_workers=0', 'dataset.train_dataset.text_dim=128',
+                                    'dataset.train_dataset.num_samples=16', 'dataset.train_dataset.shuffle=true',
+                                    'optimizer.lr=1.0e-3', 'scheduler.t_warmup=0ba', 'trainer.log_every=1',
+                                    f'trainer.save_folder={folder}', 'trainer.save_interval=3ba'] + list(extra))
+
+    full = train(cfg(tmp_path / 'a', 'trainer.max_duration=6ba'))
+    part = train(cfg(tmp_path / 'b', 'trainer.max_duration=3ba'))
+    assert part.batch_idx == 3
+    ck = os.path.join(tmp_path, 'b', 'ba3-rank0.pt')
+    st = torch.load(ck, map_location='cpu')['state']
+    assert 'rng' in st and st['batch'] == 3
+    torch.manual_seed(999)            # a resumed process starts from unrelated generator states
+    torch.cuda.manual_seed_all(999)
+    res = train(cfg(tmp_path / 'b', 'trainer.max_duration=6ba', f'trainer.load_path={ck}'))
+    assert res.batch_idx == 6
+    lf = {d['batch']: d['loss/train/total'] for d in full.logs if 'loss/train/total' in d}
+    lr = {d['batch']: d['loss/train/total'] for d in res.logs if 'loss/train/total' in d}
+    assert sorted(lr) == [4, 5, 6]
+    for b in (4, 5, 6):
+        assert lf[b] == lr[b], (b, lf[b], lr[b])
+    assert torch.equal(full.model.unet.master, res.model.unet.master)
+    assert torch.equal(full.model.unet.exp_avg_sq, res.model.unet.exp_avg_sq)
+
+
 def test_auto_microbatch_fits_memory(dev, monkeypatch):
     """device_train_microbatch_size: auto (the YAML default) must bound the microbatch by free HBM instead of taking the
     whole per-device batch (Composer's 'auto' shrinks until it fits)."""

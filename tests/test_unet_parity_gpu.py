@@ -32,6 +32,19 @@ def _build(cfg_name, dev, seed=17):
     return O, ocfg, sd, model
 
 
+# bounds: <= 2 x the margins measured on MI355X (profiles/r03_parity_margins.json), never looser than round 2's
+TOL_TINY = {'pred_rel': 2e-2, 'loss_abs': 1e-3, 'grad_rel': 6e-2, 'matrix_cos': 0.98, 'vector_rel': 6e-2}
+TOL_FULL8 = {'pred_rel': 2e-2, 'loss_abs': 1e-3, 'grad_rel': 6e-2, 'matrix_cos': 0.97}
+
+
+def _record(case, tol, **kv):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from parity_margins import record
+    record(case, tolerances=tol, **kv)
+
+
 def _rel(a, b):
     return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-20)).item()
 
@@ -60,27 +73,32 @@ def test_tiny_train_step_parity(dev):
     assert pred.shape == latents.shape and target.shape == latents.shape
     assert torch.equal(ts.cpu(), t)
     e = _rel(pred.cpu(), pred_ref)
-    assert e < 2e-2, f'eps-prediction rel-L2 {e}'
     loss = model.loss(out, batch)
-    assert abs(loss.item() - loss_ref.item()) < 1e-3, (loss.item(), loss_ref.item())
+    dl = abs(loss.item() - loss_ref.item())
     loss.backward()
     torch.cuda.synchronize()
     got = {k: p.grad.detach().float().cpu() for k, p in model.unet.named_parameters()}
     num = sum(((got[k] - grads_ref[k])**2).sum().item() for k in grads_ref)
     den = sum((grads_ref[k]**2).sum().item() for k in grads_ref)
-    assert math.sqrt(num / den) < 6e-2, f'global grad rel-L2 {math.sqrt(num / den)}'
-    bad = []
+    grel = math.sqrt(num / den)
+    worst = (None, 1.0)
     for k, gr in grads_ref.items():
         if gr.dim() < 2 or gr.norm() == 0:
             continue
         cos = torch.nn.functional.cosine_similarity(got[k].flatten(), gr.flatten(), dim=0).item()
-        if cos < 0.98:
-            bad.append((k, cos))
-    assert not bad, bad[:10]
+        if cos < worst[1]:
+            worst = (k, cos)
     # bias / norm vectors: aggregate check
     numv = sum(((got[k] - grads_ref[k])**2).sum().item() for k in grads_ref if grads_ref[k].dim() == 1)
     denv = sum((grads_ref[k]**2).sum().item() for k in grads_ref if grads_ref[k].dim() == 1)
-    assert math.sqrt(numv / denv) < 6e-2
+    vrel = math.sqrt(numv / denv)
+    _record('tiny_s16_b2', TOL_TINY, pred_rel_l2=e, loss_abs_delta=dl, grad_rel_l2=grel, worst_matrix_cosine=worst[1],
+            worst_matrix=worst[0], vector_grads_rel_l2=vrel)
+    assert e < TOL_TINY['pred_rel'], f'eps-prediction rel-L2 {e}'
+    assert dl < TOL_TINY['loss_abs'], (loss.item(), loss_ref.item())
+    assert grel < TOL_TINY['grad_rel'], f'global grad rel-L2 {grel}'
+    assert worst[1] >= TOL_TINY['matrix_cos'], worst
+    assert vrel < TOL_TINY['vector_rel'], vrel
 
 
 def test_tiny_v_prediction_and_diffusers_call(dev):
@@ -138,9 +156,8 @@ def test_full_sd2_base_forward_and_grads(dev):
     model.unet.zero_grad()
     out = model(batch, timesteps=t.to(dev), noise=noise.to(dev))
     e = _rel(out[0].cpu(), pred_ref)
-    assert e < 2e-2, f'eps rel-L2 {e}'
     loss = model.loss(out, batch)
-    assert abs(loss.item() - loss_ref.item()) < 1e-3
+    dl = abs(loss.item() - loss_ref.item())
     loss.backward()
     torch.cuda.synchronize()
     num = den = 0.0
@@ -154,8 +171,13 @@ def test_full_sd2_base_forward_and_grads(dev):
             c = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item()
             if c < worst[0]:
                 worst = (c, k)
-    assert math.sqrt(num / den) < 6e-2, math.sqrt(num / den)
-    assert worst[0] > 0.97, worst
+    grel = math.sqrt(num / den)
+    _record('full_width_s8_b1_all_686_gradients', TOL_FULL8, pred_rel_l2=e, loss_abs_delta=dl, grad_rel_l2=grel,
+            worst_matrix_cosine=worst[0], worst_matrix=worst[1])
+    assert e < TOL_FULL8['pred_rel'], f'eps rel-L2 {e}'
+    assert dl < TOL_FULL8['loss_abs']
+    assert grel < TOL_FULL8['grad_rel'], grel
+    assert worst[0] >= TOL_FULL8['matrix_cos'], worst
 
 
 def test_batched_transpose_matches_per_tensor(dev):
