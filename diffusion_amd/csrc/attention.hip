@@ -41,6 +41,17 @@ struct AttnParams {
 //    half - four distinct 64-B quarters of the bank span.
 // Until round 3 the row image (key (r>>1)&7) and the transposed-read image (key bit 1 only) were separate copies of the same
 // tile: twice the LDS-DMA requests (the per-step request block is wave time with the matrix pipe idle) and twice the LDS.
+// Diagnostic build only (-DDA_STAMPS, tools/attn_stamps.py): waves 0 and 3 of the first workgroups of the dK/dV kernel keep
+// the shader clock of five points of a query step in scalar registers and store them after the step's barrier
+// (8 slots per (workgroup, wave, step)); never compiled into the shipped library.
+#ifdef DA_STAMPS
+__device__ unsigned long long* g_attn_stamp_buf;
+__device__ int g_attn_stamp_wgs;
+#define ASTAMP(v) v = __builtin_amdgcn_s_memtime()
+#else
+#define ASTAMP(v) do {} while (0)
+#endif
+
 constexpr int TR_LD = 128;
 DEVINL int swz_key(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 DEVINL int tr_off(int row, int bytecol) { return row * TR_LD + (bytecol ^ (swz_key(row) << 4)); }
@@ -54,9 +65,11 @@ DEVINL int swz128(int row, int chunk) { return row * 128 + ((chunk ^ swz_key(row
 // and then joins the halves.
 DEVINL void tr_frag_issue(unsigned img_off, int row0, int col0, int lane, short4v& t0, short4v& t1) {
   const int gg = lane >> 4, dgrp = gg & 1, hh = gg >> 1, qq = (lane >> 2) & 3, pp = lane & 3;
-  const unsigned a = img_off + tr_off(row0 + 4 * hh + qq, (col0 + 16 * dgrp + 4 * pp) * 2);
+  const int row = row0 + 4 * hh + qq, bc = (col0 + 16 * dgrp + 4 * pp) * 2;
+  const unsigned a = img_off + tr_off(row, bc);
   t0 = lds_tr16_b64_asm(a);
-  t1 = lds_tr16_b64_asm(a + 8 * TR_LD);
+  // row + 8 flips bit 3 of the row = bit 1 of swz_key = byte bit 5 of the column (image offsets are multiples of 128 B)
+  t1 = lds_tr16_b64_asm((a ^ 32u) + 8 * TR_LD);
 }
 DEVINL bf16x8 tr_frag_join(short4v t0, short4v t1) {
   typedef __attribute__((ext_vector_type(8))) short short8v;
@@ -418,7 +431,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------
 constexpr int KV_STAGE = 2 * 32 * 128 + 2 * 32 * 4;  // Q, dO images (read by rows and transposed); L2, delta
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
+// NW = waves per workgroup: 4 (128 keys, two workgroups per CU) or 8 (256 keys, one per CU: the Q / dO tiles are requested
+// once for twice the keys and every wave issues one LDS-DMA piece per step instead of two).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnParams p) {
+  static_assert(NW == 4 || NW == 8, "waves per workgroup");
   // dynamic LDS on purpose: against a static __shared__ array the compiler treats every LDS-DMA as a possibly
   // aliasing pending LDS write and puts s_waitcnt vmcnt(0) in front of the next ds_read, exposing the whole DMA latency
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 * KV_STAGE
@@ -427,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
   const int h = lane >> 5, r = lane & 31;
   int blk, hd, b;
   xcd_block_id(blk, hd, b);
-  const int key = blk * 128 + wave * 32 + r;
+  const int key = blk * (32 * NW) + wave * 32 + r;
   const bool kv = key < p.Nk;
 
   bf16x8 kf[4], vf[4];
@@ -446,17 +463,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
   // 55 % of its wave-cycles waiting (skipping the loads made it 31 % faster).  Wave w fills rows 8w..8w+7 of the
   // two images (Q, dO); wave 0 also fetches the 32 L2 and 32 delta values.
   const int nt = (p.Nq + 31) / 32;
-  const int drow = wave * 8 + (lane >> 3), pc = lane & 7;
+  const int drow = (wave & 3) * 8 + (lane >> 3), pc = lane & 7;
   const int lc = (pc ^ swz_key(drow)) * 8;                 // source element offset behind physical chunk pc
   const bf16* qp = p.Q + ((long)b * p.Nq + drow) * p.ldq + hd * 64;
   const bf16* dop = p.dO + ((long)b * p.Nq + drow) * p.lddo + hd * 64;
   const float* statp = (lane < 32 ? p.L2 : p.Delta) + ((long)b * p.H + hd) * p.Nq + (lane & 31);
   const char* zero = reinterpret_cast<const char*>(g_attn_zero);
   auto dma = [&](int t, int st) {  // tiles are requested in order: the pointers advance by one tile per call
-    char* S = smem + st * KV_STAGE + wave * 1024;
+    char* S = smem + st * KV_STAGE + (wave & 3) * 1024;
     const bool ok = t * 32 + drow < p.Nq;
-    dma16(ok ? (const void*)(qp + lc) : (const void*)zero, S);
-    dma16(ok ? (const void*)(dop + lc) : (const void*)zero, S + 4096);
+    if (NW == 4 || wave < 4) dma16(ok ? (const void*)(qp + lc) : (const void*)zero, S);
+    if (NW == 4 || wave >= 4) dma16(ok ? (const void*)(dop + lc) : (const void*)zero, S + 4096);
     if (wave == 0) {
       const bool ok2 = t * 32 + (lane & 31) < p.Nq;
       dma4(ok2 ? (const void*)statp : (const void*)zero, smem + st * KV_STAGE + 2 * 4096);
@@ -465,11 +482,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
     dop += 32 * p.lddo;
     statp += 32;
   };
-  // wait until at most the DMAs of the newest requested tile are outstanding (2 per wave, 3 on wave 0), then barrier
+  // wait until at most the DMAs of the newest requested tile are outstanding (8 / NW per wave, one more on wave 0), then
+  // barrier
   auto sync_tiles = [&](bool newest_in_flight) {
     if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (NW == 4) {
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -479,6 +502,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
   if (nt > 1) dma(1, 1);
   sync_tiles(nt > 1);
   for (int t = 0; t < nt; ++t) {
+#ifdef DA_STAMPS
+    unsigned long long st0, st1, st2, st3, st4;
+#endif
+    ASTAMP(st0);
     if (t + 2 < nt) dma(t + 2, (t + 2) % 3);  // its stage was last read in step t-1, released by that step's barrier
     const char* Qs = smem + (t % 3) * KV_STAGE;
     const char* Os = Qs + 4096;
@@ -501,6 +528,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);     // S[q][key]
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[ks], dp, 0, 0, 0);   // dP[q][key]
     }
+    __builtin_amdgcn_sched_barrier(0);
+    ASTAMP(st1);  // S / dP products issued
     // the transposed dO / Q fragments do not depend on the softmax arithmetic below: request them now (asm form, so the
     // compiler does not guard them with a wait for the tile DMA issued at the top of the step) and wait after it
     short4v to0[2][2], to1[2][2], tq0[2][2], tq1[2][2];
@@ -528,6 +557,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
     // rows beyond Nq in the last tile: Q = dO = 0, L2 = delta = 0 -> p = 1, dP - delta = 0, dS = 0, and dO^T.P adds 0.
     bf16x8 pf[2] = {pack8(pr, 0), pack8(pr, 1)};
     bf16x8 dsf[2] = {pack8(s, 0), pack8(s, 1)};
+    ASTAMP(st2);  // softmax arithmetic issued
     lds_wait_for<0>(to0[0][0], to0[0][1], to1[0][0], to1[0][1], tq0[0][0], tq0[0][1], tq1[0][0], tq1[0][1], to0[1][0],
                     to0[1][1], to1[1][0], to1[1][1], tq0[1][0], tq0[1][1], tq1[1][0], tq1[1][1]);
 #pragma unroll
@@ -537,7 +567,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
       dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tq0[s2][0], tq0[s2][1]), dsf[s2], dk0, 0, 0, 0);
       dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tq1[s2][0], tq1[s2][1]), dsf[s2], dk1, 0, 0, 0);
     }
+    ASTAMP(st3);  // dV / dK products issued
     sync_tiles(t + 2 < nt);  // tile t+1 has landed; everyone is done reading stage t % 3
+    ASTAMP(st4);
+#ifdef DA_STAMPS
+    {
+      const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      if (g_attn_stamp_buf && wg < g_attn_stamp_wgs && (wave == 0 || wave == 3) && lane == 0 && t < 32) {
+        unsigned long long* o = g_attn_stamp_buf + (((long)wg * 2 + (wave == 3)) * 32 + t) * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4;
+      }
+    }
+#endif
   }
   if (kv) {
     bf16* kp = p.dK + ((long)b * p.Nk + key) * p.lddk + hd * 64;
@@ -563,6 +604,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
 int check(long ld) { return (ld & 7) ? 1 : 0; }
 
 }  // namespace
+
+#ifdef DA_STAMPS
+extern "C" int da_debug_set_attn_stamps(void* buf, int wgs) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp_buf), &buf, sizeof(buf)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp_wgs), &wgs, sizeof(wgs)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int da_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
                            long ldo, float* L2, int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
@@ -612,7 +660,13 @@ extern "C" int da_attn_bwd(const void* Q, long ldq, const void* K, long ldk, con
   p.scale = scale; p.sc = scale * 1.4426950408889634f;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 2 * DQ_STAGE, stream, p);
   DA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Nk + 127) / 128, H, B), dim3(256), 3 * KV_STAGE, stream, p);
+#ifndef DA_DKV_WAVES8_MIN_NK
+#define DA_DKV_WAVES8_MIN_NK (1 << 30)   // keys from which the 8-wave form of the dK/dV kernel runs (default: never)
+#endif
+  if (Nk >= DA_DKV_WAVES8_MIN_NK)
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<8>, dim3((Nk + 255) / 256, H, B), dim3(512), 3 * KV_STAGE, stream, p);
+  else
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3((Nk + 127) / 128, H, B), dim3(256), 3 * KV_STAGE, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

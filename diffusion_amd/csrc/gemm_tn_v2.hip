@@ -406,12 +406,35 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   }
 }
 
-// dW[n][k'] += sum_split slab[tile(n, k')][split][n % 320][k' % BK]   (4 consecutive k' per thread)
+// dW[n][k'] += sum_split slab[tile(n, k')][split][n % 320][k' % BK]   (4 consecutive k' per thread): blocks [0, main_blocks).
+// Blocks behind them (one per 16 bias elements, resident beside the others) reduce the bias-gradient partials:
+// dbias[n] += sum_split bslab[tn][split][n % 320]; 16 lanes share an n (splits l, l + 16, ... on two chains), then a fixed
+// butterfly - the same additions in the same order every run.
 template <int BK>
-__global__ __launch_bounds__(256) void tn_slab_reduce_kernel(GemmTN2Params p) {
+__global__ __launch_bounds__(256) void tn_slab_reduce_kernel(GemmTN2Params p, int main_blocks) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int n = ((int)blockIdx.x - main_blocks) * 16 + grp;
+    if (n < p.N) {
+      const int tn = n / T2_BN;
+      const float* src = p.bslab + ((long)tn * p.splits) * T2_BN + (n - tn * T2_BN);
+      float a0 = 0.f, a1 = 0.f;
+      int sp = l;
+      for (; sp + 16 < p.splits; sp += 32) {
+        a0 += src[(long)sp * T2_BN];
+        a1 += src[(long)(sp + 16) * T2_BN];
+      }
+      if (sp < p.splits) a0 += src[(long)sp * T2_BN];
+      float a = a0 + a1;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
+      if (l == 0) p.dbias[n] += a;
+    }
+    return;
+  }
   const int kq = p.Kt >> 2;
   const long total = (long)p.N * kq;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)main_blocks * 256) {
     const int n = (int)(i / kq);
     const int kc = (int)(i - (long)n * kq) * 4;
     const int tn = n / T2_BN, tk = kc / BK;
@@ -429,20 +452,6 @@ __global__ __launch_bounds__(256) void tn_slab_reduce_kernel(GemmTN2Params p) {
     for (int u = 0; sp < p.splits; ++sp, ++u) acc[u & 7] += *reinterpret_cast<const f32x4*>(src + (long)sp * T2_BN * BK);
     f32x4* dst = reinterpret_cast<f32x4*>(p.dW + (long)n * p.Kt + kc);
     *dst += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-  }
-  // bias gradient: dbias[n] += sum_split bslab[tn][split][n % 320]; 16 lanes share an n (splits l, l + 16, ...), then a
-  // fixed butterfly - the same additions in the same order every run
-  if (p.dbias) {
-    const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
-    for (int n = blockIdx.x * 16 + grp; n < p.N; n += gridDim.x * 16) {
-      const int tn = n / T2_BN;
-      const float* src = p.bslab + ((long)tn * p.splits) * T2_BN + (n - tn * T2_BN);
-      float a = 0.f;
-      for (int sp = l; sp < p.splits; sp += 16) a += src[(long)sp * T2_BN];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
-      if (l == 0) p.dbias[n] += a;
-    }
   }
 }
 
@@ -504,7 +513,8 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
     const long total = (long)p.N * (p.Kt >> 2);
     long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(tn_slab_reduce_kernel<BK>, dim3((int)blocks), dim3(256), 0, stream, p);
+    const int bias_blocks = p.dbias ? (p.N + 15) / 16 : 0;
+    hipLaunchKernelGGL(tn_slab_reduce_kernel<BK>, dim3((int)blocks + bias_blocks), dim3(256), 0, stream, p, (int)blocks);
     DA_CHECK_LAUNCH();
   }
   return DA_OK;
