@@ -426,16 +426,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, key-major: dK, dV.  Workgroup = 128 keys (4 waves x 32), sweeps all queries in 32-row tiles
+// backward, key-major: dK, dV.  Workgroup = 128 keys (4 waves x 32), sweeps all queries in 32-row steps, QT rows per tile
 // (three LDS stages filled by DMA two tiles ahead, one barrier per tile).
 // ------------------------------------------------------------------------------------------------
-constexpr int KV_STAGE = 2 * 32 * 128 + 2 * 32 * 4;  // Q, dO images (read by rows and transposed); L2, delta
+// QT = query rows per tile: one LDS-DMA request block and one barrier per tile, QT / 32 sub-steps of 32 queries inside it
+// (64 from 128 queries up: +3-4.5 % on the 256- to 9,216-token shapes with identical bits - half the barriers, and the
+// dV / dK products of one sub-step run beside the loads and S / dP products of the next; 32 below: the 64-token level
+// lost 3 %).  Stage = Q, dO images (read by rows and transposed) + L2, delta.
+constexpr int kv_stage(int QT) { return 2 * QT * 128 + 2 * QT * 4; }
 
-// NW = waves per workgroup: 4 (128 keys, two workgroups per CU) or 8 (256 keys, one per CU: the Q / dO tiles are requested
-// once for twice the keys and every wave issues one LDS-DMA piece per step instead of two).
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnParams p) {
-  static_assert(NW == 4 || NW == 8, "waves per workgroup");
+// (An 8-wave form - 256 keys per workgroup, one workgroup per CU, half the tile requests per key - measured 0...-10 % against
+// two 4-wave workgroups per CU, gpurun_out/ab_attn2.txt: the two unsynchronised workgroups overlap better than one wide one.)
+template <int KV_QT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
+  constexpr int NW = 4, KV_SUB = KV_QT / 32, KV_STAGE = kv_stage(KV_QT);
+  static_assert(KV_QT == 32 || KV_QT == 64, "query rows per tile");
   // dynamic LDS on purpose: against a static __shared__ array the compiler treats every LDS-DMA as a possibly
   // aliasing pending LDS write and puts s_waitcnt vmcnt(0) in front of the next ds_read, exposing the whole DMA latency
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 * KV_STAGE
@@ -458,11 +463,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnParams p) 
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
 
-  // Q / dO tiles (32 queries) reach LDS by DMA, three stages, issued TWO tiles ahead: a 32-query step lasts about one
+  // Q / dO tiles (QT queries) reach LDS by DMA, three stages, issued TWO tiles ahead: a 32-query step lasts about one
   // global-load latency, and with the register-staged prefetch consumed at the end of the same step the kernel spent
-  // 55 % of its wave-cycles waiting (skipping the loads made it 31 % faster).  Wave w fills rows 8w..8w+7 of the
-  // two images (Q, dO); wave 0 also fetches the 32 L2 and 32 delta values.
-  const int nt = (p.Nq + 31) / 32;
+  // 55 % of its wave-cycles waiting (skipping the loads made it 31 % faster).  Wave w fills rows 8w..8w+7 of each 32-row
+  // block of the two images (Q, dO); wave 0 also fetches the block's 32 L2 and 32 delta values.
+  const int nt = (p.Nq + KV_QT - 1) / KV_QT;
   const int drow = (wave & 3) * 8 + (lane >> 3), pc = lane & 7;
   const int lc = (pc ^ swz_key(drow)) * 8;                 // source element offset behind physical chunk pc
   const bf16* qp = p.Q + ((long)b * p.Nq + drow) * p.ldq + hd * 64;
@@ -471,28 +476,26 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnParams p) 
   const char* zero = reinterpret_cast<const char*>(g_attn_zero);
   auto dma = [&](int t, int st) {  // tiles are requested in order: the pointers advance by one tile per call
     char* S = smem + st * KV_STAGE + (wave & 3) * 1024;
-    const bool ok = t * 32 + drow < p.Nq;
-    if (NW == 4 || wave < 4) dma16(ok ? (const void*)(qp + lc) : (const void*)zero, S);
-    if (NW == 4 || wave >= 4) dma16(ok ? (const void*)(dop + lc) : (const void*)zero, S + 4096);
-    if (wave == 0) {
-      const bool ok2 = t * 32 + (lane & 31) < p.Nq;
-      dma4(ok2 ? (const void*)statp : (const void*)zero, smem + st * KV_STAGE + 2 * 4096);
+#pragma unroll
+    for (int sub = 0; sub < KV_SUB; ++sub) {
+      const bool ok = t * KV_QT + sub * 32 + drow < p.Nq;
+      dma16(ok ? (const void*)(qp + sub * 32 * p.ldq + lc) : (const void*)zero, S + sub * 4096);
+      dma16(ok ? (const void*)(dop + sub * 32 * p.lddo + lc) : (const void*)zero, S + KV_QT * 128 + sub * 4096);
+      if (wave == 0) {
+        const bool ok2 = t * KV_QT + sub * 32 + (lane & 31) < p.Nq;
+        dma4(ok2 ? (const void*)(statp + sub * 32) : (const void*)zero, smem + st * KV_STAGE + 2 * KV_QT * 128 + sub * 256);
+      }
     }
-    qp += 32 * p.ldq;
-    dop += 32 * p.lddo;
-    statp += 32;
+    qp += KV_QT * p.ldq;
+    dop += KV_QT * p.lddo;
+    statp += KV_QT;
   };
-  // wait until at most the DMAs of the newest requested tile are outstanding (8 / NW per wave, one more on wave 0), then
-  // barrier
+  // wait until at most the DMAs of the newest requested tile are outstanding (2 per sub-step and wave, one more on
+  // wave 0), then barrier
   auto sync_tiles = [&](bool newest_in_flight) {
     if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (NW == 4) {
-      if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-      if (wave == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    }
+    else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * KV_SUB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KV_SUB) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -507,11 +510,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnParams p) 
 #endif
     ASTAMP(st0);
     if (t + 2 < nt) dma(t + 2, (t + 2) % 3);  // its stage was last read in step t-1, released by that step's barrier
-    const char* Qs = smem + (t % 3) * KV_STAGE;
-    const char* Os = Qs + 4096;
+#pragma unroll
+    for (int sub = 0; sub < KV_SUB; ++sub) {
+    const char* Qs = smem + (t % 3) * KV_STAGE + sub * 4096;
+    const char* Os = Qs + KV_QT * 128;
     const char* Qt = Qs;  // the same images, read transposed
     const char* Ot = Os;
-    const float* Ls = reinterpret_cast<const float*>(Qs + 2 * 4096);
+    const float* Ls = reinterpret_cast<const float*>(smem + (t % 3) * KV_STAGE + 2 * KV_QT * 128 + sub * 256);
     const float* Ds = Ls + 32;
     // the row constants -delta[q] are the START values of the dP accumulators (row q of register i: acc_row)
     f32x16 s, dp;
@@ -566,6 +571,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnParams p) 
       dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(to1[s2][0], to1[s2][1]), pf[s2], dv1, 0, 0, 0);
       dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tq0[s2][0], tq0[s2][1]), dsf[s2], dk0, 0, 0, 0);
       dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tq1[s2][0], tq1[s2][1]), dsf[s2], dk1, 0, 0, 0);
+    }
     }
     ASTAMP(st3);  // dV / dK products issued
     sync_tiles(t + 2 < nt);  // tile t+1 has landed; everyone is done reading stage t % 3
@@ -660,13 +666,10 @@ extern "C" int da_attn_bwd(const void* Q, long ldq, const void* K, long ldk, con
   p.scale = scale; p.sc = scale * 1.4426950408889634f;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 2 * DQ_STAGE, stream, p);
   DA_CHECK_LAUNCH();
-#ifndef DA_DKV_WAVES8_MIN_NK
-#define DA_DKV_WAVES8_MIN_NK (1 << 30)   // keys from which the 8-wave form of the dK/dV kernel runs (default: never)
-#endif
-  if (Nk >= DA_DKV_WAVES8_MIN_NK)
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<8>, dim3((Nk + 255) / 256, H, B), dim3(512), 3 * KV_STAGE, stream, p);
+  if (Nq >= 128)
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3((Nk + 127) / 128, H, B), dim3(256), 3 * kv_stage(64), stream, p);
   else
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3((Nk + 127) / 128, H, B), dim3(256), 3 * KV_STAGE, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, dim3((Nk + 127) / 128, H, B), dim3(256), 3 * kv_stage(32), stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

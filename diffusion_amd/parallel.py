@@ -61,6 +61,13 @@ class BucketedAllReducer:
             raise ValueError(f'collective must be allreduce|rs_ag and payload fp32|bf16, got {self.collective}, {self.payload}')
         self.overlap = (os.environ.get('DA_DP_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
         self._stage = {}
+        # CUs left to the collective WHILE one is in flight (da_set_option("reserve_cus")): set when the first bucket of a
+        # step is handed to RCCL, cleared in flush().  Kernels are enqueued in order, so everything enqueued between the two
+        # - the part of backward that runs beside the exchange - sizes its one-round grids to #CUs - R.  Held for the whole
+        # step it measured -7 % at one GPU (tile counts are multiples of 256, so 248 workgroups walk 33 rounds' worth in 34);
+        # scoped to the overlap window it costs that on ~1/3 of the step.  The trainer sets it (DA_DP_RESERVE_CUS).
+        self.reserve_cus = 0
+        self._reserved = False
 
     def _exchange(self, view: torch.Tensor):
         """Sum ``view`` over the ranks, in place, stream-ordered on the current stream (RCCL: ``wait()`` only makes
@@ -94,6 +101,11 @@ class BucketedAllReducer:
             dist.all_gather_into_tensor(stage, shard, group=self.group, async_op=True).wait()
         view.copy_(stage[:n])
 
+    def _set_reserve(self, r: int):
+        from . import ops
+        ops.set_option('reserve_cus', int(r))
+        self._reserved = r > 0
+
     @property
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if self.enabled else 1
@@ -110,6 +122,8 @@ class BucketedAllReducer:
         if not self.enabled and self.on_bucket is None:
             return
         view = self.flat[lo:hi]
+        if self.enabled and self.reserve_cus and not self._reserved and self.overlap:
+            self._set_reserve(self.reserve_cus)
         if self.stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -143,6 +157,8 @@ class BucketedAllReducer:
                 self.hi = lo
         self._launch(0, self.hi)
         self.hi = 0
+        if self._reserved:
+            self._set_reserve(0)
         for h in self.handles:
             h.wait()
         if self.stream is not None and (self.enabled or self.on_bucket is not None):

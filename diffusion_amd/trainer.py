@@ -114,14 +114,17 @@ class Trainer:
         # SD-2-base-256.yaml:95-96).  On by default when there IS an exchange to hide (world > 1); at world 1 it measured
         # neutral (196.4 vs 196.6 ms/step: the slices only take CUs from the backward GEMMs), so one launch.  DA_SLICED_ADAMW=0/1.
         env = os.environ.get('DA_SLICED_ADAMW')
-        self.sliced_optimizer = (self.world > 1) if env is None else (env == '1')
+        self.sliced_optimizer = self.reducer.enabled if env is None else (env == '1')
         # Multi-GPU: leave R CUs to the RCCL channels of the overlapping all-reduce, so grids sized to one round of the
         # chip (persistent GEMM tile walks, weight-gradient pixel splits) do not spill into a second round when a
-        # collective holds a CU.  Priced at world 1 in DESIGN.md section 6.  DA_DP_RESERVE_CUS=R overrides (0 = whole chip).
-        self.reserve_cus = int(os.environ.get('DA_DP_RESERVE_CUS', '8' if self.world > 1 else '0'))
-        if self.reserve_cus or 'DA_DP_RESERVE_CUS' in os.environ:
+        # collective holds a CU.  Applied by the reducer only while buckets are in flight (parallel.py); priced in
+        # DESIGN.md section 6.  DA_DP_RESERVE_CUS=R overrides (0 = whole chip); DA_DP_RESERVE_ALWAYS=1 holds it all step.
+        self.reserve_cus = int(os.environ.get('DA_DP_RESERVE_CUS', '8' if self.reducer.enabled else '0'))
+        self.reducer.reserve_cus = self.reserve_cus
+        if os.environ.get('DA_DP_RESERVE_ALWAYS') == '1':
             from . import ops
             ops.set_option('reserve_cus', self.reserve_cus)
+            self.reducer.reserve_cus = 0
         self.base_lr = self.optimizer.param_groups[0]['lr']
         self.global_batch_size = None
         self.logs: List[dict] = []

@@ -44,6 +44,7 @@ def main():
         torch.save({'grad': (model.unet.grad.detach().cpu() * scale), 'before': before,
                     'after': model.unet.master.detach().cpu().clone(), 'loss': float(loss.item()),
                     'buckets': len(tr.reducer.launched), 'world': world, 'reducer_enabled': tr.reducer.enabled,
+                    'reserve_cus': tr.reserve_cus, 'sliced': tr.sliced_optimizer,
                     'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None)}, out)
     import torch.distributed as dist
     if dist.is_initialized():

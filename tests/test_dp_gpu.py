@@ -56,8 +56,11 @@ def test_rccl_calls_execute_in_a_one_rank_group(single, tmp_path, collective, pa
     """A 1-GPU box cannot hold two RCCL ranks, but it can run the RCCL code path itself: backend 'nccl' (= RCCL) with
     device_id, bucketed collectives on the side stream, HSA_ENABLE_IPC_MODE_LEGACY=0 - in a world of one, where the sum
     over ranks is the identity, so the step must reproduce the plain single-process step."""
+    # DA_DP_RESERVE_CUS=0: with CUs reserved for the collective the weight-gradient pixel splits (and so the order of their
+    # fixed-order sums) differ from the whole-chip run - covered by test_reserved_cus_and_sliced_adamw_... below
     env = {'DA_DP_FORCE': '1', 'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1',
-           'MASTER_PORT': '29618', 'DA_DP_COLLECTIVE': collective, 'DA_DP_PAYLOAD': payload}
+           'MASTER_PORT': '29618', 'DA_DP_COLLECTIVE': collective, 'DA_DP_PAYLOAD': payload, 'DA_DP_RESERVE_CUS': '0',
+           'DA_SLICED_ADAMW': '0'}
     one = _run(str(tmp_path / 'one.pt'), 1, env)
     assert one['backend'] == 'nccl' and one['reducer_enabled'] and one['buckets'] >= 3
     if payload == 'fp32':   # the sum over one rank is the identity and every reduction on the path is fixed-order: bit equality
@@ -68,3 +71,18 @@ def test_rccl_calls_execute_in_a_one_rank_group(single, tmp_path, collective, pa
         assert rel < 5e-3, rel
         upd = ((one['after'] - single['after']).norm() / (single['after'] - single['before']).norm()).item()
         assert upd < 0.05, upd
+
+
+def test_reserved_cus_and_sliced_adamw_in_a_one_rank_rccl_group(single, tmp_path):
+    """The multi-GPU defaults on the RCCL path: R CUs left to the collective while buckets are in flight
+    (DA_DP_RESERVE_CUS, default 8 when an exchange runs) and the AdamW slices issued behind each bucket on the side stream
+    (default when an exchange runs).  Same step as the plain run up to the summation order of the re-split weight-gradient
+    grids; the sliced optimizer step lands on the same weights."""
+    env = {'DA_DP_FORCE': '1', 'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1',
+           'MASTER_PORT': '29619', 'DA_DP_RESERVE_CUS': '16', 'DA_SLICED_ADAMW': '1'}
+    one = _run(str(tmp_path / 'one.pt'), 1, env)
+    assert one['backend'] == 'nccl' and one['reducer_enabled'] and one['reserve_cus'] == 16 and one['sliced']
+    rel = ((one['grad'] - single['grad']).norm() / single['grad'].norm()).item()
+    assert rel < 1e-5, rel
+    upd = ((one['after'] - single['after']).norm() / (single['after'] - single['before']).norm()).item()
+    assert upd < 1e-2, upd
