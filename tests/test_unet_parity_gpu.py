@@ -1,8 +1,9 @@
 """End-to-end parity of the HIP U-Net training step against the CPU oracle (oracle/unet_oracle.py) on identical
 (latents, timesteps, text_embeds, noise).  Tolerances (north_star: "stated fp32/bf16 tolerance"):
   * eps-prediction: relative L2 error <= 2e-2 (bf16 activations/weights, fp32 accumulation)
-  * loss: |loss_hip - loss_oracle| <= 1e-3 (BASELINE.json: "per-step loss within 1e-3 of the reference")
-  * gradients: global relative L2 error <= 6e-2 and per-tensor cosine similarity >= 0.98 on every weight matrix"""
+  * loss: |loss_hip - loss_oracle| <= 5e-4 (BASELINE.json: "per-step loss within 1e-3 of the reference")
+  * gradients: global relative L2 error <= 4e-2 and per-tensor cosine similarity >= 0.9957 on every weight matrix
+  (TOL_TINY / TOL_FULL8 below: at most twice the measured margins, recorded by tests/parity_margins.py)"""
 import math
 
 import pytest
@@ -32,9 +33,11 @@ def _build(cfg_name, dev, seed=17):
     return O, ocfg, sd, model
 
 
-# bounds: <= 2 x the margins measured on MI355X (profiles/r03_parity_margins.json), never looser than round 2's
-TOL_TINY = {'pred_rel': 2e-2, 'loss_abs': 1e-3, 'grad_rel': 6e-2, 'matrix_cos': 0.98, 'vector_rel': 6e-2}
-TOL_FULL8 = {'pred_rel': 2e-2, 'loss_abs': 1e-3, 'grad_rel': 6e-2, 'matrix_cos': 0.97}
+# bounds: <= 2 x the margins measured on MI355X (profiles/r03_parity_margins.json: tiny 1.12e-2 / 1.7e-4 / 2.08e-2 / 0.99786 /
+# 1.15e-2; full width at 8x8 1.04e-2 / 1.0e-4 / 2.08e-2 / 0.99905).  The loss bound is 5e-4 everywhere: |loss - oracle| is the
+# difference of two O(1) numbers at bf16 noise level (1e-6 ... 2.4e-4 over the cases), half of BASELINE.json's 1e-3.
+TOL_TINY = {'pred_rel': 2e-2, 'loss_abs': 5e-4, 'grad_rel': 4e-2, 'matrix_cos': 0.9957, 'vector_rel': 2.3e-2}
+TOL_FULL8 = {'pred_rel': 2e-2, 'loss_abs': 5e-4, 'grad_rel': 4e-2, 'matrix_cos': 0.9981}
 
 
 def _record(case, tol, **kv):
