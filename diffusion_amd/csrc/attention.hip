@@ -89,6 +89,29 @@ DEVINL bf16x8 pack8(const f32x16& x, int s) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 DEVINL f32x2 pair(const f32x16& v, int i) { return f32x2{v[2 * i], v[2 * i + 1]}; }
 DEVINL void set_pair(f32x16& v, int i, f32x2 x) { v[2 * i] = x.x; v[2 * i + 1] = x.y; }
+// Scalar forms of the pair arithmetic for the FORWARD kernel: beside MFMAs a v_pk_*_f32 costs more than the two plain
+// instructions it replaces (MI355X_MICROARCH.md, cycle constants), and the forward - one exp and ~4 other VALU ops per score
+// against 8 MFMAs per 32x32 tile - measured +4...6 % at 256 / 1,024 tokens and +-1 % elsewhere with them (gpurun_out/
+// ab_attn4.txt); the backward kernels measured +-2 % either way and keep the packed forms.  The empty asm keeps the
+// compiler's SLP pass from re-pairing them.
+DEVINL f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
+  float x = fmaf(a.x, b.x, c.x), y = fmaf(a.y, b.y, c.y);
+  asm("" : "+v"(x));
+  asm("" : "+v"(y));
+  return f32x2{x, y};
+}
+DEVINL f32x2 mul2(f32x2 a, f32x2 b) {
+  float x = a.x * b.x, y = a.y * b.y;
+  asm("" : "+v"(x));
+  asm("" : "+v"(y));
+  return f32x2{x, y};
+}
+DEVINL f32x2 add2(f32x2 a, f32x2 b) {
+  float x = a.x + b.x, y = a.y + b.y;
+  asm("" : "+v"(x));
+  asm("" : "+v"(y));
+  return f32x2{x, y};
+}
 DEVINL f32x2 exp2_2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
 
 DEVINL float max3(float a, float b, float c) {
@@ -237,8 +260,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       const f32x2 al2 = {alpha, alpha};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        set_pair(o0, i, pair(o0, i) * al2);
-        set_pair(o1, i, pair(o1, i) * al2);
+        set_pair(o0, i, mul2(pair(o0, i), al2));
+        set_pair(o1, i, mul2(pair(o1, i), al2));
       }
       m = mn;
     }
@@ -247,11 +270,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const f32x2 e0 = exp2_2(__builtin_elementwise_fma(pair(s0, i), sc2, msc2));
-      const f32x2 e1 = exp2_2(__builtin_elementwise_fma(pair(s1, i), sc2, msc2));
+      const f32x2 e0 = exp2_2(fma2(pair(s0, i), sc2, msc2));
+      const f32x2 e1 = exp2_2(fma2(pair(s1, i), sc2, msc2));
       set_pair(s0, i, e0);
       set_pair(s1, i, e1);
-      ls2 += e0 + e1;
+      ls2 = add2(ls2, add2(e0, e1));
     }
     l += ls2.x + ls2.y;
     lds_wait_for<0>(tv[0][0][0], tv[0][0][1], tv[0][1][0], tv[0][1][1], tv[0][2][0], tv[0][2][1], tv[0][3][0], tv[0][3][1],

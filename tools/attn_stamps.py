@@ -32,9 +32,10 @@ for it in range(3):
                            D.data_ptr(), dQ.data_ptr(), Cc, dK.data_ptr(), Cc, dV.data_ptr(), Cc, B, H, Nq, Nk, 0.125, st) == 0
 torch.cuda.synchronize()
 s = buf.view(WGS, 2, 32, 8).cpu().double()
-nt = min(32, (Nq + 31) // 32)
-names = ['request next tile + S/dP products issued', 'transposed reads requested + softmax arithmetic issued',
-         'wait for fragments + dV/dK products issued', 'tile wait + barrier']
+QT = 64 if Nq >= 128 else 32   # query rows per tile of the dK/dV kernel (attention.hip)
+nt = min(32, (Nq + QT - 1) // QT)
+names = ['request next tile + first sub-step + S/dP products of the last sub-step issued', 'transposed reads requested + softmax arithmetic issued (last sub-step)',
+         'wait for fragments + dV/dK products issued (last sub-step)', 'tile wait + barrier']
 for w, wn in ((0, 'wave 0'), (1, 'wave 3')):
     x = s[:, w, 4:nt - 2]            # steady-state steps
     ok = (x[..., 0] > 0).all(dim=-1)
