@@ -17,6 +17,17 @@
 #include "diffusion_amd.h"
 
 
+// NT2_CT (convolution forms, i.e. !EARLY): the 16x16x32 products are taken TRANSPOSED (W fragment as the first MFMA operand),
+// so a lane's four accumulator registers of a tile are four consecutive COLUMNS of one output row instead of four rows of
+// one column: the epilogue stages a strip with one ds_write_b128 per tile (5 per strip) instead of four ds_write_b32 (20
+// per strip; the LDS store path's 64 B/clk was ~0.55 us of a ~2 us strip).  Same products, same sums, bit-identical output.
+// Measured (tools/lib_ab.py nt, gpurun_out/ab_nt_ct.txt): 3x3 convs +1.3...+3.6 %; the persistent linear / GEGLU forms
+// -0.4...-3.7 % (their epilogue runs beside the next tile's first DMA and is VALU-issue, not LDS-store, bound), so those
+// keep the row-of-column form.  0 = the old form everywhere (A/B).
+#ifndef NT2_CT
+#define NT2_CT 1
+#endif
+
 int g_nt_persist = -1;  // da_set_option("gemm_nt_persist", n): resident workgroups of the persistent forms (-1 = #CUs, 0 = off)
 // da_set_option("reserve_cus", R): CUs left to somebody else - the RCCL channels of the gradient all-reduce that overlaps
 // backward in a multi-GPU job.  Every grid that is sized to ONE ROUND of the chip (the persistent tile walks here, the
@@ -116,6 +127,7 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
 template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU, bool EARLY, int MF = 16>
 DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   constexpr int NW = WM * WN;
+  constexpr bool CT = NT2_CT && !EARLY && MF == 16 && GEGLU == 0;  // transposed products, see NT2_CT
   constexpr int V2_BM = MF * MT * WM, V2_BK = BK;
   static_assert((NW == 16 || NW == 8 || NW == 4) && (BK == 64 || BK == 32), "wave grid");
   static_assert(MF == 16 || (MF == 32 && GEGLU == 0 && BK == 64), "MFMA shape");
@@ -348,7 +360,8 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = CT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     } else {
       // two 16-deep slices per half-step; lane = (row % 32, k-half): the 16 rows a ds_read_b128 lane group touches are 8
       // even + 8 odd ones with 8 distinct (row >> 1) & 7 keys, so the 64-B-step swizzle stays conflict-free
@@ -379,7 +392,15 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   STAMP(1);
   __syncthreads();
   STAMP(2);
-  {
+  if constexpr (CT) {  // register e of tile j = column wn*16*NT + j*16 + 4*(lane >> 4) + e
+    const float* brow = reinterpret_cast<const float*>(smem + BIAS_OFF + bbuf * (BN * 4)) + wn * (MF * NT) + (fresh_lane() >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const f32x4 b4 = fold_bias ? *reinterpret_cast<const f32x4*>(brow + j * MF) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][j] = b4;
+    }
+  } else {
     const float* brow = reinterpret_cast<const float*>(smem + BIAS_OFF + bbuf * (BN * 4)) + wn * (MF * NT) + (fresh_lane() & (MF - 1));
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -446,10 +467,15 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
     for (int i = 0; i < MT; ++i) {
       float* ew = strips + wm * GSTRIP;
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j) {
+        if constexpr (CT) {
+          *reinterpret_cast<f32x4*>(&ew[(el & 15) * GLD + wn * (16 * NT) + j * 16 + (el >> 4) * 4]) = acc[i][j];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          ew[((el >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (el & 15)] = acc[i][j][e];
+          for (int e = 0; e < 4; ++e)
+            ew[((el >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (el & 15)] = acc[i][j][e];
+        }
+      }
       lds_barrier();
 #pragma unroll
       for (int pss = 0; pss < GPASSES; ++pss) {
@@ -507,10 +533,15 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
         }
       }
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j) {
+        if constexpr (CT) {
+          *reinterpret_cast<f32x4*>(&ew[(el & 15) * GLD + wn * (16 * NT) + j * 16 + (el >> 4) * 4]) = acc[i][j];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          ew[((el >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (el & 15)] = acc[i][j][e];
+          for (int e = 0; e < 4; ++e)
+            ew[((el >> 4) * 4 + e) * GLD + wn * (16 * NT) + j * 16 + (el & 15)] = acc[i][j][e];
+        }
+      }
       lds_barrier();
 #pragma unroll
       for (int pss = 0; pss < GPASSES; ++pss) {
@@ -587,12 +618,17 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   for (int i = 0; i < NSI; ++i) {  // strip i = rows [i * SR, i * SR + SR) of the wave's row block
     float* ew = strips + ((EPI_DB ? (i & 1) * WM : 0) + wm) * STRIP;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NT; ++j) {
+      if constexpr (CT) {
+        *reinterpret_cast<f32x4*>(&ew[(el & 15) * EPI_LD + wn * (16 * NT) + j * 16 + (el >> 4) * 4]) = acc[i][j];
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if constexpr (MF == 16) ew[((el >> 4) * 4 + e) * EPI_LD + wn * (16 * NT) + j * 16 + (el & 15)] = acc[i][j][e];
-        else ew[((el >> 5) * 4 + e) * EPI_LD + wn * (32 * NT) + j * 32 + (el & 31)] = acc[i / 4][j][(i & 3) * 4 + e];
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (MF == 16) ew[((el >> 4) * 4 + e) * EPI_LD + wn * (16 * NT) + j * 16 + (el & 15)] = acc[i][j][e];
+          else ew[((el >> 5) * 4 + e) * EPI_LD + wn * (32 * NT) + j * 32 + (el & 31)] = acc[i / 4][j][(i & 3) * 4 + e];
+        }
       }
+    }
     lds_barrier();
 #pragma unroll
     for (int pss = 0; pss < PASSES; ++pss) {

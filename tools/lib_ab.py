@@ -3,6 +3,7 @@ per cent, so numbers from different gpurun boxes are not comparable).
 
   python tools/lib_ab.py <old.so> attn [cand.so ...]   attention forward / backward at the U-Net's shapes
   python tools/lib_ab.py <old.so> tn [B]               weight-gradient GEMM at the U-Net's shapes (batch B, default 256)
+  python tools/lib_ab.py <old.so> nt [B]               forward / dgrad GEMM (convs, linears with bias + residual, fused GEGLU)
 With candidates, each is timed against <old.so>; without, the shipped library is the candidate.
 
 <old.so> is any earlier build, e.g.  git show <rev>:diffusion_amd/csrc/attention.hip > /tmp/a.hip ; hipcc ... -o tools/_ab/old.so
@@ -124,6 +125,55 @@ def run(old, new, what):
             print(f'tn M={M} N={N} Kt={ks * ks * Cin} k{ks}: {ta:7.0f} -> {tb:7.0f} us ({fl / tb / 1e6:5.0f} TF/s, {100 * (ta / tb - 1):+5.1f} %) '
                   f'rel dW {rel:.1e} db {relb:.1e}', flush=True)
             del dy, x, dws
+    elif what == 'nt':
+        Bt = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 256
+        ws = torch.empty(32 * 1024 * 1024, device=dev)
+        # (pixels per image, N, Cin, H, W, ksize, residual)
+        shapes = [(1024, 320, 320, 32, 32, 3, 0), (1024, 320, 320, 32, 32, 3, 1), (256, 640, 640, 16, 16, 3, 0), (64, 1280, 1280, 8, 8, 3, 1),
+                  (16, 1280, 1280, 4, 4, 3, 0), (1024, 320, 960, 32, 32, 3, 0), (1024, 320, 320, 1, 1, 1, 1), (1024, 960, 320, 1, 1, 1, 0),
+                  (256, 640, 640, 1, 1, 1, 1), (64, 1280, 1280, 1, 1, 1, 1), (1024, 320, 1280, 1, 1, 1, 1), (256, 640, 2560, 1, 1, 1, 1)]
+        for hw, N, Cin, H, W, ks, res in shapes:
+            M = Bt * hw
+            a = torch.randn(M, Cin, device=dev).to(BF); w = (torch.randn(N, ks * ks * Cin, device=dev) * 0.05).to(BF)
+            bias = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev).to(BF)
+            outs = [torch.empty(M, N, device=dev, dtype=BF) for _ in range(2)]
+            hin, win = (1, 1) if ks == 1 else (H, W)
+
+            def run(lib, o):
+                rc = lib.da_gemm_nt(a.data_ptr(), Cin, w.data_ptr(), o.data_ptr(), N, bias.data_ptr(), 0, 0, r.data_ptr() if res else 0,
+                                    N if res else 0, M, N, ks * ks * Cin, Cin, hin, win, hin, win, ks, 0, 0, 1.0, ws.data_ptr(), ws.numel(), st)
+                assert rc == 0
+            ta, tb = ab(lambda: run(old, outs[0]), lambda: run(new, outs[1]))
+            fl = 2.0 * M * N * ks * ks * Cin
+            print(f'nt M={M} N={N} K={ks * ks * Cin} k{ks} res{res}: {ta:7.0f} -> {tb:7.0f} us ({fl / tb / 1e6:5.0f} TF/s, {100 * (ta / tb - 1):+5.1f} %) '
+                  f'equal {torch.equal(outs[0], outs[1])}', flush=True)
+            del a, w, r, outs
+        for hw, C in ((1024, 320), (256, 640), (64, 1280)):   # fused GEGLU forward / backward of the feed-forward
+            M = Bt * hw
+            inner = 4 * C
+            a = torch.randn(M, C, device=dev).to(BF); w = (torch.randn(2 * inner, C, device=dev) * 0.05).to(BF)
+            bias = torch.randn(2 * inner, device=dev)
+            F = [torch.empty(M, 2 * inner, device=dev, dtype=BF) for _ in range(2)]
+            G = [torch.empty(M, inner, device=dev, dtype=BF) for _ in range(2)]
+
+            def fw(lib, i):
+                assert lib.da_gemm_nt_geglu(a.data_ptr(), C, w.data_ptr(), F[i].data_ptr(), 2 * inner, G[i].data_ptr(), inner, bias.data_ptr(),
+                                            M, inner, C, st) == 0
+            ta, tb = ab(lambda: fw(old, 0), lambda: fw(new, 1))
+            fl = 2.0 * M * 2 * inner * C
+            print(f'geglu fwd M={M} C={C}: {ta:7.0f} -> {tb:7.0f} us ({fl / tb / 1e6:5.0f} TF/s, {100 * (ta / tb - 1):+5.1f} %) '
+                  f'equal {torch.equal(F[0], F[1]) and torch.equal(G[0], G[1])}', flush=True)
+            dy = torch.randn(M, C, device=dev).to(BF); wt = (torch.randn(inner, C, device=dev) * 0.05).to(BF)
+            dF = [torch.empty(M, 2 * inner, device=dev, dtype=BF) for _ in range(2)]
+
+            def bw(lib, i):
+                assert lib.da_gemm_nt_geglu_bwd(dy.data_ptr(), C, wt.data_ptr(), F[0].data_ptr(), 2 * inner, dF[i].data_ptr(), 2 * inner, M,
+                                                inner, C, st) == 0
+            ta, tb = ab(lambda: bw(old, 0), lambda: bw(new, 1))
+            fl = 2.0 * M * inner * C
+            print(f'geglu bwd M={M} C={C}: {ta:7.0f} -> {tb:7.0f} us ({fl / tb / 1e6:5.0f} TF/s, {100 * (ta / tb - 1):+5.1f} %) '
+                  f'equal {torch.equal(dF[0], dF[1])}', flush=True)
+            del a, w, F, G, dy, wt, dF
     else:
         raise SystemExit(__doc__)
 
