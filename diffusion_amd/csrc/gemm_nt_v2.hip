@@ -34,6 +34,7 @@ int g_nt_persist = -1;  // da_set_option("gemm_nt_persist", n): resident workgro
 // weight-gradient pixel splits in gemm_tn_v2.hip, the cost model's round count in gemm_nt.hip) is sized to #CUs - R
 // instead, so that a CU taken by a collective does not push a whole-CU workgroup into a second round.  0 = whole chip.
 int g_reserve_cus = 0;
+int g_nt_persist_conv = 1;  // da_set_option("gemm_nt_persist_conv", 0 | 1): the persistent tile walk for 3x3 convolutions
 int da_usable_cus(int cus) {
   int n = cus - g_reserve_cus;
   return n < 32 ? 32 : n;
@@ -61,6 +62,8 @@ struct GemmNT2Params {
   long ldg;
   int inner;                     // GEGLU variant: hidden width; W rows [0, inner) = value, [inner, 2*inner) = gate
   int total_blocks;              // persistent (EARLY) form: tiles vblock = blockIdx.x, += gridDim.x, < total_blocks
+  FastDiv div_hw, div_w;         // exact m / (Hout*Wout) and rem / Wout for m < 2^24 (persistent convolution form: a runtime
+                                 // divisor's reciprocal would live in a VGPR across the tile walk)
   int korder;                    // 3x3 K-loop order: 0 = tap-major (k = tap*Cin + c, as W is laid out), 1 = channel-chunk-major
                                  // with the 9 taps innermost (see the K-loop comment)
 };
@@ -124,7 +127,9 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
 // cycles whatever its shape (MI355X_MICROARCH.md, cycle constants) - with four waves per SIMD also issuing 18-24
 // ds_read_b128 and the LDS-DMA pieces of the next stage every K-step, the 16x16x32 form spends 1,280 of a step's 2,560
 // matrix-pipe cycles on MFMA issue alone and the step measures ~3,500.
-template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU, bool EARLY, int MF = 16>
+// PERSIST: the resident-workgroup tile walk with the next tile's first K-step requested ahead of the epilogue (LDS map below).
+// Always with EARLY; also - round 3 - for the 16-wave convolution form when a launch has more tiles than CUs.
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU, bool EARLY, int MF = 16, bool PERSIST = EARLY>
 DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   constexpr int NW = WM * WN;
   constexpr bool CT = NT2_CT && !EARLY && MF == 16 && GEGLU == 0;  // transposed products, see NT2_CT
@@ -149,8 +154,8 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   // descriptor arithmetic waiting on nothing) is in flight under the epilogue instead of in front of the next K loop.
   constexpr int EPI_LD = BN + 4;
   constexpr int STRIP = SR * EPI_LD;  // floats per strip
-  constexpr int STRIP_OFF = EARLY ? STAGE : 0;
-  constexpr int BIAS_OFF = !EARLY ? 2 * STAGE : (STAGE + WM * STRIP * 4 > 2 * STAGE ? STAGE + WM * STRIP * 4 : 2 * STAGE);
+  constexpr int STRIP_OFF = PERSIST ? STAGE : 0;
+  constexpr int BIAS_OFF = !PERSIST ? 2 * STAGE : (STAGE + WM * STRIP * 4 > 2 * STAGE ? STAGE + WM * STRIP * 4 : 2 * STAGE);
   int vblock = vblock0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -221,7 +226,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   const int ntaps = p.ksize * p.ksize;
   const bf16* abase[AJ];
   unsigned amask[AJ];
-  unsigned aoff[AJ];  // EARLY forms only
+  unsigned aoff[AJ];  // EARLY forms, and the persistent convolution form (packed descriptors)
   unsigned woff[BJ];  // bytes
   int nk, tap, c0;
   const int nk_total = p.K / V2_BK;
@@ -243,9 +248,16 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
       continue;
     }
     const int mm = mval ? m : 0;
-    const int b = mm / HWo;
-    const int rem = mm - b * HWo;
-    const int oh = rem / p.Wout;
+    int b, rem, oh;
+    if constexpr (PERSIST) {
+      b = (int)fdiv((unsigned)mm, p.div_hw);
+      rem = mm - b * HWo;
+      oh = (int)fdiv((unsigned)rem, p.div_w);
+    } else {
+      b = mm / HWo;
+      rem = mm - b * HWo;
+      oh = rem / p.Wout;
+    }
     const int ow = rem - oh * p.Wout;
     unsigned mask = ((oh & 1) << 16) | ((ow & 1) << 17);
     for (int t = 0; t < ntaps; ++t) {
@@ -254,8 +266,18 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
       const bool ok = mval && (unsigned)th < (unsigned)hlim && (unsigned)tw < (unsigned)wlim && !((th | tw) & pmask);
       mask |= (ok ? 1u : 0u) << t;
     }
-    amask[j] = mask;
     const int bh = (oh * gmul - pad) >> gshift, bw = (ow * gmul - pad) >> gshift;
+    if constexpr (PERSIST && !UPS) {
+      // persistent convolution form: the walk keeps the descriptors of a tile live next to the accumulators, so they are
+      // packed - a 32-bit byte offset from A (mod 2^32: the tap-(0,0) pixel of a border row lies before the image, the
+      // displacement of a VALID tap brings the sum back inside; the host checks the activation is < 4 GiB) and both rows'
+      // 9-bit tap masks in one register
+      aoff[j] = (unsigned)(((long)(b * p.Hin * p.Win) + (long)bh * p.Win + bw) * p.lda * 2 + (lchunk ^ swz_key<BK>(row)) * 16);
+      if (j == 0) amask[0] = mask & 0x1ffu;
+      else amask[0] |= (mask & 0x1ffu) << (9 * j);
+      continue;
+    }
+    amask[j] = mask;
     abase[j] = p.A + ((long)(b * p.Hin * p.Win) + (long)bh * p.Win + bw) * p.lda + (lchunk ^ swz_key<BK>(row)) * 8;
   }
   // B: row groups wave, wave+NW, ... (< BGROUPS): uniform base W + k0 plus a constant per-lane element offset.
@@ -300,10 +322,21 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
       // tap displacement in source pixels: r, s (stride 1 / 2) or (r+pad)/2 (dgrad of stride 2, only even taps valid)
       const int dr = (r + (gshift ? pad : 0)) >> gshift, ds = (s2 + (gshift ? pad : 0)) >> gshift;
       const long soff = (long)(dr * p.Win + ds) * p.lda + c0;
+      if constexpr (PERSIST) {
+        static_assert(AJ * 9 <= 32, "packed tap masks");
+        const char* au = reinterpret_cast<const char*>(p.A);
+        const unsigned sb = (unsigned)(soff * 2);
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) {
-        const void* src = (amask[j] & tapbit) ? (const void*)(abase[j] + soff) : (const void*)zero;
-        glds16(src, Ab + (wave * AJ + j) * 1024);
+        for (int j = 0; j < AJ; ++j) {
+          const void* src = ((amask[0] >> (9 * j)) & tapbit) ? (const void*)(au + (unsigned)(aoff[j] + sb)) : (const void*)zero;
+          glds16(src, Ab + (wave * AJ + j) * 1024);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+          const void* src = (amask[j] & tapbit) ? (const void*)(abase[j] + soff) : (const void*)zero;
+          glds16(src, Ab + (wave * AJ + j) * 1024);
+        }
       }
     } else {
       // nearest-2x upsample: source row of tap r is (oh + r - pad) >> 1, which depends on the parity of oh
@@ -320,7 +353,13 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       const int g = wave + NW * j;
-      if (BGROUPS % NW == 0 || g < BGROUPS) glds16(wb + woff[j], Bb + g * 1024);
+      if constexpr (PERSIST && !EARLY) {
+        // persistent convolution form (full column tiles only, N % BN == 0: no row clamping): row group g = wave + NW*j lies
+        // NW*RG rows of W behind group `wave` - a uniform offset on the base, ONE lane offset register for all groups
+        if (BGROUPS % NW == 0 || g < BGROUPS) glds16(wb + (size_t)j * (NW * RG) * p.K * 2 + woff[0], Bb + g * 1024);
+      } else {
+        if (BGROUPS % NW == 0 || g < BGROUPS) glds16(wb + woff[j], Bb + g * 1024);
+      }
     }
     // advance (selects, no branch): tap-inner walks the taps of one channel chunk; tap-major walks the chunks of one tap
     const int tap_n = tap + 1, c_n = c0 + V2_BK;
@@ -574,7 +613,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   // ---- epilogue: the WN waves that share a row block stage their i-th 16-row MFMA strip side by side in LDS, then
   // leave it as full BN-wide rows (640 B contiguous per row at BN 320) - per-wave strips would store and read the
   // residual in 16*NT*2-byte pieces (160 B, straddling 128-B lines), which measured ~2.4 TB/s on the K=320 linears
-  constexpr bool EPI_DB = !EARLY && 2 * WM * STRIP * 4 <= 2 * STAGE;  // double-buffered strips: one barrier per strip
+  constexpr bool EPI_DB = !PERSIST && 2 * WM * STRIP * 4 <= 2 * STAGE;  // double-buffered strips: one barrier per strip
   constexpr int CH = BN / 8;                              // 8-column chunks per row
   constexpr int TASKS = SR * CH;                          // (row, chunk) pairs per strip, shared by 64*WN lanes
   constexpr int NSI = MT * (MF == 16 ? 1 : 4);            // strips per wave: one per 16-row tile | per register quad of a 32-row tile
@@ -693,7 +732,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   load_bias(0);
   describe();
   issue(0, true);
-  if constexpr (!EARLY) {
+  if constexpr (!PERSIST) {
     kloop(0);
     epilogue(m0, n0, tn, split, 0);
   } else {
@@ -723,10 +762,10 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
 // list with stride gridDim.x inside nt2_tile, requesting the next tile's first K-step before the epilogue of the current
 // one, so neither that load nor the epilogue's stores are waited for between tiles, and no workgroup is torn down and
 // re-dispatched per tile.
-template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU = 0, bool EARLY = false, int MF = 16>
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU = 0, bool EARLY = false, int MF = 16, bool PERSIST = EARLY>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt2_kernel(GemmNT2Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY, MF>(p, blockIdx.x, smem);
+  nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY, MF, PERSIST>(p, blockIdx.x, smem);
 }
 
 // split-K finalize: out[m][n] = alpha * sum_s slab[s][m][n] + bias[n] + rowbias[image(m)][n] + R[m][n]
@@ -788,30 +827,30 @@ static int persistent_grid(int total_blocks) {
   return total_blocks < n ? total_blocks : n;
 }
 
-template <int MT, int NT, int WM, int WN, int BK, bool UPS, bool EARLY, int MF = 16>
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, bool EARLY, int MF = 16, bool PERSIST = EARLY>
 int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t stream) {
   GemmNT2Params p = p0;
   constexpr int V2_BM = MF * MT * WM, V2_BK = BK, NTHREADS = 64 * WM * WN;
   constexpr int BN = MF * NT * WN;
   constexpr int STAGE = V2_BM * V2_BK * 2 + BN * V2_BK * 2, STRIPS = WM * (MF == 16 ? 16 : 8) * (BN + 4) * 4;
   // one tile per workgroup: 2 stages + bias row, strips inside the stages; persistent: strips behind stage 0, 2 bias rows
-  constexpr int SMEM = EARLY ? (STAGE + STRIPS > 2 * STAGE ? STAGE + STRIPS : 2 * STAGE) + 2 * BN * 4 : 2 * STAGE + BN * 4;
+  constexpr int SMEM = PERSIST ? (STAGE + STRIPS > 2 * STAGE ? STAGE + STRIPS : 2 * STAGE) + 2 * BN * 4 : 2 * STAGE + BN * 4;
   static_assert(2 * STAGE >= STRIPS && SMEM <= 160 * 1024, "LDS map of nt2_tile");
   p.tiles_m = (p.M + V2_BM - 1) / V2_BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   static unsigned long long attr_done = 0;  // one bit per device
-  if (da_ensure_dyn_smem((const void*)gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
+  if (da_ensure_dyn_smem((const void*)gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF, PERSIST>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
   const int nk_total = p.K / V2_BK;
   p.splits = splits > 1 ? splits : 1;
   p.ksteps_per_split = (nk_total + p.splits - 1) / p.splits;
   p.splits = (nk_total + p.ksteps_per_split - 1) / p.ksteps_per_split;  // no empty splits
   p.slab_stride = (long)p.M * p.N;
   p.total_blocks = p.tiles_m * p.tiles_n * p.splits;
-  const int grid = EARLY ? persistent_grid(p.total_blocks) : p.total_blocks;
+  const int grid = PERSIST ? persistent_grid(p.total_blocks) : p.total_blocks;
   if (p.splits > 1) {
     GemmNT2Params pk = p;
     pk.C = ws;  // partial slabs
-    hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF>), dim3(grid), dim3(NTHREADS), SMEM,
+    hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF, PERSIST>), dim3(grid), dim3(NTHREADS), SMEM,
                        stream, pk);
     DA_CHECK_LAUNCH();
     const long total = (long)p.M * (p.N >> 3);
@@ -821,7 +860,7 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
     DA_CHECK_LAUNCH();
     return DA_OK;
   }
-  hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF>), dim3(grid), dim3(NTHREADS), SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF, PERSIST>), dim3(grid), dim3(NTHREADS), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -851,6 +890,15 @@ int launch_v2(const GemmNT2Params& p, int splits, float* ws, hipStream_t stream)
     // (its A rows are addressed by 32-bit byte offsets from the base: larger activations take the generic form)
     if (p.ksize == 1 && (long)p.M * p.lda * 2 < (1L << 32)) return launch_v2_mode<MT, NT, WM, WN, BK, false, true, MF>(p, splits, ws, stream);
   }
+  if constexpr (WM * WN == 16 && MF == 16 && MT == 4 && NT == 5) {
+    // 3x3 convolutions on the 16-wave 256x320 form with more tiles than CUs: resident workgroups walk the tile list and
+    // request the next tile's first K-step (and build its gather descriptors) ahead of the current tile's epilogue
+    // (da_set_option("gemm_nt_persist_conv", 0) = one tile per workgroup, as before round 3)
+    const long tiles = (long)((p.M + 255) / 256) * ((p.N + 319) / 320) * (splits > 1 ? splits : 1);
+    if (g_nt_persist_conv && g_nt_persist != 0 && p.ksize == 3 && tiles > da_usable_cus(256) && p.N % 320 == 0 && p.M < (1 << 24) &&
+        (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.lda * 2 < (1L << 32))
+      return launch_v2_mode<MT, NT, WM, WN, BK, false, false, MF, true>(p, splits, ws, stream);
+  }
   return launch_v2_mode<MT, NT, WM, WN, BK, false, false, MF>(p, splits, ws, stream);
 }
 
@@ -875,6 +923,8 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
   p.G = nullptr; p.ldg = 0; p.inner = 0;
   p.korder = g_nt_korder;
   p.total_blocks = 0;
+  p.div_hw = make_fastdiv((unsigned)(Hout * Wout));
+  p.div_w = make_fastdiv((unsigned)Wout);
   if (variant == 10) return launch_v2<8, 5, 2, 4, 64>(p, splits, ws, stream);
   if (variant == 11) return launch_v2<4, 10, 2, 2, 32>(p, 1, ws, stream);  // 128 x 320 x 32, 4 waves, 2 workgroups / CU
   if (variant == 12) return launch_v2<4, 5, 4, 4, 64>(p, splits, ws, stream);  // 256 x 320 x 64, 16 waves (4 / SIMD)
@@ -902,6 +952,7 @@ extern "C" int da_gemm_nt_geglu(const void* A, long lda, const void* W, void* F,
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
   p.G = (bf16*)G; p.ldg = ldg; p.inner = inner; p.korder = 0; p.total_blocks = 0;
+  p.div_hw = p.div_w = make_fastdiv(1u);
   return launch_v2_geglu<1>(p, stream);
 }
 
@@ -922,5 +973,6 @@ extern "C" int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, c
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
   p.G = (bf16*)const_cast<void*>(F); p.ldg = ldf; p.inner = inner; p.korder = 0; p.total_blocks = 0;
+  p.div_hw = p.div_w = make_fastdiv(1u);
   return launch_v2_geglu<2>(p, stream);
 }

@@ -68,6 +68,8 @@ int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* 
  *   "gemm_nt_splitk"    1 (default) split-K allowed | 0 never split
  *   "gemm_nt_persist"   -1 (default) linears / fused GEGLU run as one resident workgroup per CU walking the tile list |
  *                       n > 0 that many resident workgroups | 0 one workgroup per tile
+ *   "gemm_nt_persist_conv" 1 (default) 3x3 convolutions with more tiles than CUs also run as a resident tile walk (next tile's
+ *                       descriptors + first K-step ahead of the epilogue; +0...1.4 %, bit-identical) | 0 one workgroup per tile
  *   "gemm_tn_variant"   0 auto | 1 the 128x128x32 wgrad kernel | 2 the 320x192x64 LDS-DMA wgrad kernel
  *   "reserve_cus"       R in [0, 128] (default 0): every grid sized to one round of the chip (persistent GEMM tile walks,
  *                       weight-gradient pixel splits, the dispatch cost model) uses #CUs - R, leaving R CUs to the RCCL
