@@ -17,6 +17,12 @@
 
 int da_usable_cus(int cus);  // gemm_nt_v2.hip: #CUs less da_set_option("reserve_cus")
 
+// CT (template flag of the kernel): the products are taken TRANSPOSED (X fragment as the first MFMA operand): a lane's four
+// accumulator registers of a tile are then four consecutive k' of one n, and the epilogue touches the 320 x 192 fp32 tile
+// in 30 16-byte accesses per lane instead of 120 4-byte ones.  Same products, same sums, bit-identical dW.  Measured
+// (tools/lib_ab.py tn, gpurun_out/ab_tn_ct.txt): the UNSPLIT tiles - a read-add-write of dW, the 1280-channel 3x3 layers -
+// +5.5...+23.7 %; split tiles (plain slab stores) +-1 %, and -2.6...-6.8 % on the K' <= 640 linears.  So: CT = unsplit.
+
 namespace {
 
 struct GemmTN2Params {
@@ -61,7 +67,7 @@ DEVINL void glds16_tn(const void* gsrc, char* lds_dst) {
 // arithmetic: dY loads are uniform base + a constant lane offset, X loads add one select on a precomputed validity
 // mask.  The generic path (strided / upsampled gathers, ragged M) recomputes coordinates each step: ~105 VALU
 // instructions per step that run on every wave with the matrix pipe idle.
-template <int T2_BK, bool FAST>
+template <int T2_BK, bool FAST, bool CT>
 __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   constexpr int T2_SB = T2_BK * 2;
   constexpr int T2_B_BYTES = T2_MS * T2_SB;
@@ -320,7 +326,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     }
     if (do_bias) {
 #pragma unroll
-      for (int i = 0; i < 5; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
+      for (int i = 0; i < 5; ++i)
+        accb[i] = CT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], accb[i], 0, 0, 0)
+                     : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
     }
 #pragma unroll
     for (int jh = 0; jh < 2; ++jh) {
@@ -342,7 +350,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
 #pragma unroll
         for (int jj = 0; jj < JT / 2; ++jj)
           acc[i][jh * (JT / 2) + jj] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bfr[jj], acc[i][jh * (JT / 2) + jj], 0, 0, 0);
+              CT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], a[i], acc[i][jh * (JT / 2) + jj], 0, 0, 0)
+                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bfr[jj], acc[i][jh * (JT / 2) + jj], 0, 0, 0);
     }
   };
 
@@ -371,6 +380,39 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     }
   }
 
+  if constexpr (CT) {
+    // accumulator register e of tile (i, j): n = wa*80 + i*16 + (lane & 15), k' = wb*16*JT + j*16 + 4*(lane >> 4) + e
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const int nl = wa * 80 + i * 16 + (lane & 15), kl = wb * (16 * JT) + j * 16 + (lane >> 4) * 4;
+        const int n = n0 + nl, kc = k0 + kl;
+        if (p.slab && p.splits > 1) {
+          *reinterpret_cast<f32x4*>(p.slab + (((long)(tn * p.tiles_k + tk) * p.splits + split) * T2_BN + nl) * T2_BK + kl) = acc[i][j];
+        } else if (n < p.N && kc < p.Kt) {  // Kt % 8 == 0 and kc % 4 == 0: the four k' are inside together
+          float* dst = p.dW + (long)n * p.Kt + kc;
+          if (p.splits == 1) {
+            *reinterpret_cast<f32x4*>(dst) += acc[i][j];  // sole owner of this tile: plain read-add-write
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, acc[i][j][e]);
+          }
+        }
+      }
+    if (do_bias && lane < 16) {  // every register of accb[i] holds the column sum of n = wa*80 + i*16 + (lane & 15)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int nl = wa * 80 + i * 16 + lane, n = n0 + nl;
+        if (p.slab && p.splits > 1) p.bslab[((long)tn * p.splits + split) * T2_BN + nl] = accb[i][0];  // summed by the reduce kernel
+        else if (n < p.N) {
+          if (p.splits == 1) p.dbias[n] += accb[i][0];  // the only workgroup with this (tn, tk == 0)
+          else unsafeAtomicAdd(p.dbias + n, accb[i][0]);  // no workspace: order-dependent last bits (as dW above)
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -496,8 +538,9 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
   mps = ((mps + T2_MS - 1) / T2_MS) * T2_MS;
   p.splits = (p.M + mps - 1) / mps;
   p.m_per_split = mps;
-  static unsigned long long attr_done = 0;  // one bit per device
-  if (da_ensure_dyn_smem((const void*)gemm_tn2_kernel<BK, FAST>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
+  static unsigned long long attr_done = 0, attr_done_ct = 0;  // one bit per device
+  if (da_ensure_dyn_smem((const void*)gemm_tn2_kernel<BK, FAST, false>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
+  if (da_ensure_dyn_smem((const void*)gemm_tn2_kernel<BK, FAST, true>, SMEM, &attr_done_ct) != DA_OK) return DA_ERR_LAUNCH;
   p.slab = p.bslab = nullptr;
   {
     const long tile_floats = (long)tiles * p.splits * T2_BN * BK;
@@ -507,7 +550,8 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
       p.bslab = ws + tile_floats;
     }
   }
-  hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST>), dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
+  if (p.splits == 1) hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST, true>), dim3(tiles), dim3(512), SMEM, stream, p);
+  else hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST, false>), dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   if (p.slab) {
     const long total = (long)p.N * (p.Kt >> 2);
