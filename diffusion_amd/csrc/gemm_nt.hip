@@ -252,6 +252,7 @@ extern int g_nt_korder;  // gemm_nt_v2.hip
 extern int g_nt_persist;
 extern int g_reserve_cus;
 extern int g_nt_persist_conv;
+extern int g_grad_overwrite;
 int da_usable_cus(int cus);
 static int g_nt_variant = 0;
 static int g_nt_mfma32 = 0;   // da_set_option("gemm_nt_mfma32", 0 never | -1 for K <= 320 | 1 always): the 256x320 form on
@@ -371,6 +372,10 @@ extern "C" int da_set_option(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_nt_persist_conv")) {
     g_nt_persist_conv = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "grad_overwrite")) {
+    g_grad_overwrite = value ? 1 : 0;
     return DA_OK;
   }
   if (key && !strcmp(key, "reserve_cus")) {

@@ -24,6 +24,7 @@ struct GemmTNParams {
   FastDiv div_hw, div_w;
   int tiles_n, tiles_k, splits, m_per_split;
   float* slab;  // splits > 1 with a workspace: partial tiles [tile][split][128][128] fp32, summed by tn1_slab_reduce_kernel
+  int overwrite;  // da_set_option("grad_overwrite"): dW = ... instead of dW += ...
 };
 
 constexpr int TN_BM = 32;                 // pixels per step
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNParams p) {
           p.slab[(((long)(tn * p.tiles_k + tk) * p.splits + split) * 128 + nl) * 128 + kl] = acc[i][j][e];
         } else if (n < p.N && kc < p.Kt) {
           float* dst = p.dW + (long)n * p.Kt + kc;
-          if (p.splits == 1) *dst += acc[i][j][e];   // sole owner of the tile
+          if (p.splits == 1) *dst = p.overwrite ? acc[i][j][e] : *dst + acc[i][j][e];   // sole owner of the tile
           else unsafeAtomicAdd(dst, acc[i][j][e]);   // no workspace: order-dependent last bits
         }
       }
@@ -193,7 +194,8 @@ __global__ __launch_bounds__(256) void tn1_slab_reduce_kernel(GemmTNParams p) {
     }
     for (int u = 0; sp < p.splits; ++sp, ++u) acc[u & 7] += *reinterpret_cast<const f32x4*>(src + (long)sp * 128 * 128);
     f32x4* dst = reinterpret_cast<f32x4*>(p.dW + (long)n * p.Kt + kc);
-    *dst += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    const f32x4 sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    *dst = p.overwrite ? sum : *dst + sum;
   }
 }
 
@@ -205,6 +207,11 @@ int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X
                            long ws_floats, hipStream_t stream);
 int da_gemm_tn_v2_fast_period(int M, int N, int Hin, int Win, int Hout, int Wout, int mode);
 int g_tn_variant = 0;  // 0 auto, 1 force v1 (128x128x32), 2 force v2 (320x192x64); da_set_option
+// da_set_option("grad_overwrite", 1): every gradient-PRODUCING entry point (da_gemm_tn_wgrad incl. its bias gradient,
+// da_colsum_accum, da_image_colsum's db, the dgamma / dbeta of da_groupnorm_bwd / da_layernorm_bwd) writes its outputs
+// instead of adding to them.  The trainer sets it for the first microbatch of a step, which then needs neither the 3.46 GB
+// zero fill of the flat gradient nor the read half of 866 M read-add-writes.  0 (default) = accumulate, as the header says.
+int g_grad_overwrite = 0;
 
 static bool tn_takes_v2(int M, int N, int Kt) {
   // measured (tools/tn_ab.py, microbatch 16 / 64): the 320x192x64 kernel wins from 1,024 pixels up (1.1-2.3x), and at 256
@@ -262,7 +269,10 @@ extern "C" int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long l
   p.m_per_split = mps;
   // split tiles meet in a slab + fixed-order reduce when the caller passed a workspace (reproducible), else in atomics
   p.slab = nullptr;
+  p.overwrite = g_grad_overwrite;
   if (splits > 1 && split_ws && (long)tiles * splits * 128 * 128 <= split_ws_floats && (p.Kt & 3) == 0) p.slab = split_ws;
+  if (p.overwrite && splits > 1 && !p.slab)  // the atomic path can only add: start from zero
+    if (hipMemsetAsync(dW, 0, (size_t)N * p.Kt * sizeof(float), stream) != hipSuccess) return DA_ERR_LAUNCH;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 0, stream, p);
   DA_CHECK_LAUNCH();
   if (p.slab) {

@@ -16,6 +16,7 @@
 #include "diffusion_amd.h"
 
 int da_usable_cus(int cus);  // gemm_nt_v2.hip: #CUs less da_set_option("reserve_cus")
+extern int g_grad_overwrite;  // gemm_tn.hip
 
 // CT (template flag of the kernel): the products are taken TRANSPOSED (X fragment as the first MFMA operand): a lane's four
 // accumulator registers of a tile are then four consecutive k' of one n, and the epilogue touches the 320 x 192 fp32 tile
@@ -38,6 +39,7 @@ struct GemmTN2Params {
   float* slab;  // split > 1 with a workspace: tile partials are STORED here, [tile][split][320][BK] fp32, and summed
                // into dW by tn_slab_reduce_kernel (no atomics; fixed summation order)
   float* bslab;  // the bias-gradient partials of the same splits, [tn][split][320] fp32 (behind the tile slabs)
+  int overwrite;  // da_set_option("grad_overwrite"): dW / dbias are written, not added to
   int period;  // FAST path: the border pattern of a lane's X rows repeats every `period` 64-pixel steps
 };
 
@@ -392,8 +394,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
           *reinterpret_cast<f32x4*>(p.slab + (((long)(tn * p.tiles_k + tk) * p.splits + split) * T2_BN + nl) * T2_BK + kl) = acc[i][j];
         } else if (n < p.N && kc < p.Kt) {  // Kt % 8 == 0 and kc % 4 == 0: the four k' are inside together
           float* dst = p.dW + (long)n * p.Kt + kc;
-          if (p.splits == 1) {
-            *reinterpret_cast<f32x4*>(dst) += acc[i][j];  // sole owner of this tile: plain read-add-write
+          if (p.splits == 1) {  // sole owner of this tile: plain write / read-add-write
+            if (p.overwrite) *reinterpret_cast<f32x4*>(dst) = acc[i][j];
+            else *reinterpret_cast<f32x4*>(dst) += acc[i][j];
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, acc[i][j][e]);
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
         const int nl = wa * 80 + i * 16 + lane, n = n0 + nl;
         if (p.slab && p.splits > 1) p.bslab[((long)tn * p.splits + split) * T2_BN + nl] = accb[i][0];  // summed by the reduce kernel
         else if (n < p.N) {
-          if (p.splits == 1) p.dbias[n] += accb[i][0];  // the only workgroup with this (tn, tk == 0)
+          if (p.splits == 1) p.dbias[n] = p.overwrite ? accb[i][0] : p.dbias[n] + accb[i][0];  // the only workgroup with this (tn, tk == 0)
           else unsafeAtomicAdd(p.dbias + n, accb[i][0]);  // no workspace: order-dependent last bits (as dW above)
         }
       }
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
           p.slab[(((long)(tn * p.tiles_k + tk) * p.splits + split) * T2_BN + nl) * T2_BK + kl] = acc[i][j][e];
         } else if (n < p.N && kc < p.Kt) {
           float* dst = p.dW + (long)n * p.Kt + kc;
-          if (p.splits == 1) *dst += acc[i][j][e];  // sole owner of this tile: plain read-add-write
+          if (p.splits == 1) *dst = p.overwrite ? acc[i][j][e] : *dst + acc[i][j][e];  // sole owner of this tile
           else unsafeAtomicAdd(dst, acc[i][j][e]);
         }
       }
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
         const int nl = wa * 80 + i * 16 + (lane >> 4) * 4 + e, n = n0 + nl;
         if (p.slab && p.splits > 1) p.bslab[((long)tn * p.splits + split) * T2_BN + nl] = accb[i][e];  // summed by the reduce kernel
         else if (n < p.N) {
-          if (p.splits == 1) p.dbias[n] += accb[i][e];  // the only workgroup with this (tn, tk == 0)
+          if (p.splits == 1) p.dbias[n] = p.overwrite ? accb[i][e] : p.dbias[n] + accb[i][e];  // the only workgroup with this (tn, tk == 0)
           else unsafeAtomicAdd(p.dbias + n, accb[i][e]);  // no workspace: order-dependent last bits (as dW above)
         }
       }
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(256) void tn_slab_reduce_kernel(GemmTN2Params p, in
       float a = a0 + a1;
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
-      if (l == 0) p.dbias[n] += a;
+      if (l == 0) p.dbias[n] = p.overwrite ? a : p.dbias[n] + a;
     }
     return;
   }
@@ -493,7 +496,8 @@ __global__ __launch_bounds__(256) void tn_slab_reduce_kernel(GemmTN2Params p, in
     }
     for (int u = 0; sp < p.splits; ++sp, ++u) acc[u & 7] += *reinterpret_cast<const f32x4*>(src + (long)sp * T2_BN * BK);
     f32x4* dst = reinterpret_cast<f32x4*>(p.dW + (long)n * p.Kt + kc);
-    *dst += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    const f32x4 sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    *dst = p.overwrite ? sum : *dst + sum;
   }
 }
 
@@ -550,6 +554,11 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
       p.bslab = ws + tile_floats;
     }
   }
+  p.overwrite = g_grad_overwrite;
+  if (p.overwrite && p.splits > 1 && !p.slab) {  // the atomic path can only add: start from zero
+    if (hipMemsetAsync(p.dW, 0, (size_t)p.N * p.Kt * sizeof(float), stream) != hipSuccess) return DA_ERR_LAUNCH;
+    if (p.dbias && hipMemsetAsync(p.dbias, 0, (size_t)p.N * sizeof(float), stream) != hipSuccess) return DA_ERR_LAUNCH;
+  }
   if (p.splits == 1) hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST, true>), dim3(tiles), dim3(512), SMEM, stream, p);
   else hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST, false>), dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
   DA_CHECK_LAUNCH();
@@ -594,6 +603,7 @@ int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X
   p.div_cin = make_fastdiv((unsigned)Cin);
   p.tiles_n = p.tiles_k = p.splits = p.m_per_split = 0;
   p.slab = p.bslab = nullptr;
+  p.overwrite = 0;
   (void)variant;  // the 320x256 instantiation (160 accumulators) spills on gfx950 and lost to 320x192 everywhere
   p.period = da_gemm_tn_v2_fast_period(M, N, Hin, Win, Hout, Wout, mode);
   return p.period ? launch_tn2<192, true>(p, ws, ws_floats, stream) : launch_tn2<192, false>(p, ws, ws_floats, stream);

@@ -12,6 +12,8 @@
 #include "common.hpp"
 #include "diffusion_amd.h"
 
+extern int g_grad_overwrite;  // gemm_tn.hip: da_set_option("grad_overwrite") - write the gradient outputs instead of adding
+
 namespace {
 
 struct ChanReduceParams {
@@ -356,7 +358,7 @@ __global__ void gn_bwd_apply_kernel(const bf16* X, long ldx, const bf16* DY, lon
 // let the slices meet in fp32 atomics (order-dependent last bits in every norm / bias gradient).
 constexpr int CSF_CH = 16, CSF_RL = 64;
 __global__ __launch_bounds__(CSF_CH * CSF_RL) void chan_sum_finalize_kernel(const float* partial, int nrows, int C,
-                                                                            float* out1, float* out2) {
+                                                                            float* out1, float* out2, int overwrite) {
   __shared__ float sh[CSF_RL][CSF_CH][2];
   const int cx = threadIdx.x % CSF_CH, ry = threadIdx.x / CSF_CH;
   const int c = blockIdx.x * CSF_CH + cx;
@@ -406,8 +408,8 @@ __global__ __launch_bounds__(CSF_CH * CSF_RL) void chan_sum_finalize_kernel(cons
       ta += sh[j][cx][0];
       tq += sh[j][cx][1];
     }
-    if (out1) out1[c] += ta;
-    if (out2) out2[c] += tq;
+    if (out1) out1[c] = overwrite ? ta : out1[c] + ta;
+    if (out2) out2[c] = overwrite ? tq : out2[c] + tq;
   }
 }
 
@@ -419,7 +421,8 @@ static inline dim3 chan_sum_grid(int nrows, int C) {
 // out[b][c] = sum_chunks partial[b][chunk][c][0] (bf16, strided) ; db[c] += sum_b out[b][c] (fp32)
 // block = 16 channels x 64 image-lanes; the image-lanes meet in LDS in lane order (no atomics, reproducible)
 __global__ __launch_bounds__(CSF_CH * CSF_RL) void image_colsum_finalize_kernel(const float* partial, bf16* out, long ldo,
-                                                                                float* db, int B, int nchunks, int C) {
+                                                                                float* db, int B, int nchunks, int C,
+                                                                                int overwrite) {
   __shared__ float sh[CSF_RL][CSF_CH];
   const int cx = threadIdx.x % CSF_CH, ry = threadIdx.x / CSF_CH;
   const int c = blockIdx.x * CSF_CH + cx;
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(CSF_CH * CSF_RL) void image_colsum_finalize_kernel(
     float t = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) t += sh[j][cx];
-    db[c] += t;
+    db[c] = overwrite ? t : db[c] + t;
   }
 }
 
@@ -819,7 +822,7 @@ extern "C" int da_groupnorm_bwd(const void* X, long ldx, const void* dY, long ld
   DA_CHECK_LAUNCH();
   // dgamma[c] += sum_b s2, dbeta[c] += sum_b s1
   hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid(B * p.nchunks, C), dim3(CSF_CH * CSF_RL), 0, stream, scratch,
-                     B * p.nchunks, C, dbeta, dgamma);
+                     B * p.nchunks, C, dbeta, dgamma, g_grad_overwrite);
   DA_CHECK_LAUNCH();
   GnApplyParams ap = {};
   ap.X = (const bf16*)X; ap.ldx = ldx; ap.DY = (const bf16*)dY; ap.lddy = lddy; ap.Radd = (const bf16*)Radd; ap.ldr = ldr;
@@ -843,7 +846,7 @@ extern "C" int da_colsum_accum(const void* X, long ldx, float* out, float* scrat
   int rc = launch_chan_reduce(2, p, 1, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid(n, C), dim3(CSF_CH * CSF_RL), 0, stream, scratch, n, C, out,
-                     (float*)nullptr);
+                     (float*)nullptr, g_grad_overwrite);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -858,7 +861,7 @@ extern "C" int da_image_colsum(const void* X, long ldx, void* out, long ldo, flo
   int rc = launch_chan_reduce(2, p, B, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(image_colsum_finalize_kernel, dim3((C + CSF_CH - 1) / CSF_CH), dim3(CSF_CH * CSF_RL), 0, stream,
-                     scratch, (bf16*)out, ldo, db, B, p.nchunks, C);
+                     scratch, (bf16*)out, ldo, db, B, p.nchunks, C, g_grad_overwrite);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -912,7 +915,7 @@ extern "C" int da_layernorm_bwd(const void* X, long ldx, const void* dY, long ld
 #undef LN_BWD5
     DA_CHECK_LAUNCH();
     hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid((int)b5, C), dim3(CSF_CH * CSF_RL), 0, stream, scratch, (int)b5, C,
-                       dgamma, dbeta);
+                       dgamma, dbeta, g_grad_overwrite);
     DA_CHECK_LAUNCH();
     return DA_OK;
   }
@@ -923,7 +926,7 @@ extern "C" int da_layernorm_bwd(const void* X, long ldx, const void* dY, long ld
                      mean_rstd, scratch, M, C);
   DA_CHECK_LAUNCH();
   hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid(blocks, C), dim3(CSF_CH * CSF_RL), 0, stream, scratch, blocks, C,
-                     dgamma, dbeta);
+                     dgamma, dbeta, g_grad_overwrite);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -282,6 +282,7 @@ class UNetHIP(nn.Module):
         self._scratch = None
         self._scratch_key = None
         self.opt_step = 0
+        self._grad_fresh = False   # begin_gradient_accumulation(): the next backward overwrites the gradient buffer
         self._grad_ready_cb = None  # parallel.BucketedAllReducer.ready during the last microbatch
         import os
         self.wgrad_stream = torch.cuda.Stream() if os.environ.get('DA_WGRAD_STREAM', '0') == '1' else None
@@ -393,6 +394,18 @@ class UNetHIP(nn.Module):
 
     def zero_grad(self, set_to_none: bool = False):  # type: ignore[override]
         self.grad.zero_()
+        self._grad_fresh = False
+
+    def begin_gradient_accumulation(self):
+        """What ``zero_grad()`` is for, without the 3.46 GB fill: the NEXT backward writes every gradient instead of adding
+        to it (da_set_option("grad_overwrite"): weight / bias / norm-affine gradients are each produced by exactly one
+        launch per backward), later backwards of the same step accumulate as usual.  Alignment gaps of the flat buffer are
+        never written and stay zero.  DA_GRAD_OVERWRITE=0 falls back to the fill."""
+        import os
+        if os.environ.get('DA_GRAD_OVERWRITE', '1') == '0':
+            self.zero_grad()
+        else:
+            self._grad_fresh = True
 
     def _apply(self, fn, recurse=True):  # type: ignore[override]
         """Parameters are views of flat device buffers in kernel layout: .to()/.half()/.cuda() on an enclosing
@@ -757,6 +770,16 @@ class UNetHIP(nn.Module):
         tape, self._tape = self._tape, None
         if tape is None:
             raise RuntimeError('backward_features called without a recorded forward')
+        fresh, self._grad_fresh = getattr(self, '_grad_fresh', False), False
+        if fresh:
+            ops.set_option('grad_overwrite', 1)
+        try:
+            self._backward_walk(tape, dpred)
+        finally:
+            if fresh:
+                ops.set_option('grad_overwrite', 0)
+
+    def _backward_walk(self, tape, dpred: torch.Tensor):
         B = dpred.shape[0]
         self._dtproj = self._bf(self._tproj.shape[0], self.tproj_total)
         dskip: Dict[int, torch.Tensor] = {}

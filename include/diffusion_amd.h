@@ -71,6 +71,10 @@ int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* 
  *   "gemm_nt_persist_conv" 1 (default) 3x3 convolutions with more tiles than CUs also run as a resident tile walk (next tile's
  *                       descriptors + first K-step ahead of the epilogue; +0...1.4 %, bit-identical) | 0 one workgroup per tile
  *   "gemm_tn_variant"   0 auto | 1 the 128x128x32 wgrad kernel | 2 the 320x192x64 LDS-DMA wgrad kernel
+ *   "grad_overwrite"    0 (default) the gradient-producing entry points ADD to their outputs, as documented below | 1 they WRITE
+ *                       them (da_gemm_tn_wgrad's dW and dbias, da_colsum_accum, da_image_colsum's db, dgamma / dbeta of
+ *                       da_groupnorm_bwd / da_layernorm_bwd): set by the host around the first backward of an optimizer step,
+ *                       which then needs no zero fill of the gradient buffer
  *   "reserve_cus"       R in [0, 128] (default 0): every grid sized to one round of the chip (persistent GEMM tile walks,
  *                       weight-gradient pixel splits, the dispatch cost model) uses #CUs - R, leaving R CUs to the RCCL
  *                       channels of an overlapping gradient all-reduce (set by the trainer when world size > 1) */

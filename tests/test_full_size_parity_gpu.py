@@ -241,3 +241,16 @@ def test_two_identical_steps_give_bitwise_equal_gradients(full, dev):
     diff = (runs[0][0] != runs[1][0])
     assert not bool(diff.any()), f'{int(diff.sum())} gradient words differ between two identical steps'
     _record('determinism_s32_b2', gradient_words=int(runs[0][0].numel()), differing_words=int(diff.sum()))
+    # the trainer's zero-fill-free path: the first backward of a step WRITES every gradient (grad_overwrite).  Poison the
+    # whole flat buffer; after one such backward every one of the 686 parameter gradients must equal the zero-fill +
+    # accumulate result bit for bit (a producer that still added would leave NaNs), and a second backward must add to it.
+    ref = {k: p.grad.detach().clone() for k, p in model.unet.named_parameters()}
+    model.unet.grad.fill_(float('nan'))
+    model.unet.begin_gradient_accumulation()
+    for rep in (1, 2):
+        out = model(batch, timesteps=t.to(dev), noise=noise.to(dev))
+        model.loss(out, batch).backward()
+        torch.cuda.synchronize()
+        bad = [k for k, p in model.unet.named_parameters() if not torch.equal(p.grad, ref[k] * rep)]
+        assert not bad, (rep, len(bad), bad[:5])
+    model.unet.zero_grad()

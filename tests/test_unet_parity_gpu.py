@@ -257,3 +257,51 @@ def test_wgrad_side_stream_gives_the_same_gradients(dev, monkeypatch):
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)
     assert torch.equal(g0[0], g0[1]) and torch.equal(g1[0], g1[1])
+
+
+def test_first_backward_of_a_step_overwrites_the_gradient_buffer(dev):
+    """UNetHIP.begin_gradient_accumulation(): no zero fill - the next backward writes every gradient (each is produced by
+    exactly one launch), later ones add.  Tiny width, poisoned buffer, every parameter compared bit for bit with the
+    zero_grad() + accumulate path; also through Trainer.train_batch with two microbatches."""
+    O, ocfg, sd, model = _build('tiny', dev)
+    B, S = 4, 16
+    latents, ctx, noise, t = _inputs(B, S, ocfg.cross_attention_dim, seed=23)
+    batch = {'image_latents': latents.to(dev), 'caption_latents': ctx.to(dev)}
+    u = model.unet
+
+    def backward():
+        out = model(batch, timesteps=t.to(dev), noise=noise.to(dev))
+        model.loss(out, batch).backward()
+        torch.cuda.synchronize()
+
+    u.zero_grad()
+    backward()
+    ref = {k: p.grad.detach().clone() for k, p in u.named_parameters()}
+    u.grad.fill_(float('nan'))
+    u.begin_gradient_accumulation()
+    backward()
+    bad = [k for k, p in u.named_parameters() if not torch.equal(p.grad, ref[k])]
+    assert not bad, (len(bad), bad[:8])
+    backward()                                   # second backward of the "step": accumulates
+    bad = [k for k, p in u.named_parameters() if not torch.equal(p.grad, ref[k] * 2)]
+    assert not bad, (len(bad), bad[:8])
+    # the trainer: two microbatches, overwrite then accumulate == zero fill then accumulate twice
+    from diffusion_amd.optim import FusedAdamW
+    from diffusion_amd.trainer import Trainer
+    import os
+    fb = dict(batch, _noise=noise.to(dev), _timesteps=t.to(dev))
+    res = []
+    for flag in ('1', '0'):
+        os.environ['DA_GRAD_OVERWRITE'] = flag
+        try:
+            m2 = _build('tiny', dev)[3]
+            tr = Trainer(m2, train_dataloader=None, optimizers=FusedAdamW(lr=1e-3, unet=m2.unet), max_duration='1ba',
+                         device_train_microbatch_size=2)
+            m2.unet.grad.fill_(7.0 if flag == '1' else 0.0)    # stale values: the overwrite path must not see them
+            tr.train_batch(fb)
+            torch.cuda.synchronize()
+            res.append({k: p.grad.detach().clone() for k, p in m2.unet.named_parameters()})
+        finally:
+            os.environ.pop('DA_GRAD_OVERWRITE', None)
+    bad = [k for k in res[0] if not torch.equal(res[0][k], res[1][k])]
+    assert not bad, (len(bad), bad[:8])
