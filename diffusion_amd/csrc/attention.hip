@@ -91,8 +91,8 @@ DEVINL f32x2 pair(const f32x16& v, int i) { return f32x2{v[2 * i], v[2 * i + 1]}
 DEVINL void set_pair(f32x16& v, int i, f32x2 x) { v[2 * i] = x.x; v[2 * i + 1] = x.y; }
 // Scalar forms of the pair arithmetic for the FORWARD kernel: beside MFMAs a v_pk_*_f32 costs more than the two plain
 // instructions it replaces (MI355X_MICROARCH.md, cycle constants), and the forward - one exp and ~4 other VALU ops per score
-// against 8 MFMAs per 32x32 tile - measured +4...6 % at 256 / 1,024 tokens and +-1 % elsewhere with them (gpurun_out/
-// ab_attn4.txt); the backward kernels measured +-2 % either way and keep the packed forms.  The empty asm keeps the
+// against 8 MFMAs per 32x32 tile - measured +4...6 % at 256 / 1,024 tokens and +-1 % elsewhere with them
+// (profiles/r03_ab_attn4.txt); the backward kernels measured +-2 % either way and keep the packed forms.  The empty asm keeps the
 // compiler's SLP pass from re-pairing them.
 DEVINL f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
   float x = fmaf(a.x, b.x, c.x), y = fmaf(a.y, b.y, c.y);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 constexpr int kv_stage(int QT) { return 2 * QT * 128 + 2 * QT * 4; }
 
 // (An 8-wave form - 256 keys per workgroup, one workgroup per CU, half the tile requests per key - measured 0...-10 % against
-// two 4-wave workgroups per CU, gpurun_out/ab_attn2.txt: the two unsynchronised workgroups overlap better than one wide one.)
+// two 4-wave workgroups per CU, profiles/r03_ab_attn2.txt: the two unsynchronised workgroups overlap better than one wide one.)
 template <int KV_QT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int NW = 4, KV_SUB = KV_QT / 32, KV_STAGE = kv_stage(KV_QT);

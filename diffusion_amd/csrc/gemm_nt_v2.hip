@@ -21,7 +21,7 @@
 // so a lane's four accumulator registers of a tile are four consecutive COLUMNS of one output row instead of four rows of
 // one column: the epilogue stages a strip with one ds_write_b128 per tile (5 per strip) instead of four ds_write_b32 (20
 // per strip; the LDS store path's 64 B/clk was ~0.55 us of a ~2 us strip).  Same products, same sums, bit-identical output.
-// Measured (tools/lib_ab.py nt, gpurun_out/ab_nt_ct.txt): 3x3 convs +1.3...+3.6 %; the persistent linear / GEGLU forms
+// Measured (tools/lib_ab.py nt, profiles/r03_ab_nt_ct.txt): 3x3 convs +1.3...+3.6 %; the persistent linear / GEGLU forms
 // -0.4...-3.7 % (their epilogue runs beside the next tile's first DMA and is VALU-issue, not LDS-store, bound), so those
 // keep the row-of-column form.  0 = the old form everywhere (A/B).
 #ifndef NT2_CT

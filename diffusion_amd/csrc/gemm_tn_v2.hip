@@ -21,7 +21,7 @@ extern int g_grad_overwrite;  // gemm_tn.hip
 // CT (template flag of the kernel): the products are taken TRANSPOSED (X fragment as the first MFMA operand): a lane's four
 // accumulator registers of a tile are then four consecutive k' of one n, and the epilogue touches the 320 x 192 fp32 tile
 // in 30 16-byte accesses per lane instead of 120 4-byte ones.  Same products, same sums, bit-identical dW.  Measured
-// (tools/lib_ab.py tn, gpurun_out/ab_tn_ct.txt): the UNSPLIT tiles - a read-add-write of dW, the 1280-channel 3x3 layers -
+// (tools/lib_ab.py tn, profiles/r03_ab_tn_ct.txt): the UNSPLIT tiles - a read-add-write of dW, the 1280-channel 3x3 layers -
 // +5.5...+23.7 %; split tiles (plain slab stores) +-1 %, and -2.6...-6.8 % on the K' <= 640 linears.  So: CT = unsplit.
 
 namespace {
