@@ -660,3 +660,103 @@ def test_gelu_fwd(ops, dev):
     check(y, F.gelu(x.float()), what='gelu')
     ops.gelu_fwd(x, x)      # in place
     assert torch.equal(x, y)
+
+
+# ------------------------------------------------------------------------------------------------ process-wide options (round 3)
+def test_grad_overwrite_option_writes_instead_of_adding(ops, dev):
+    """da_set_option("grad_overwrite", 1): every gradient-producing entry point WRITES its outputs (the trainer sets it
+    around the first backward of a step, which then needs no zero fill).  Outputs poisoned with NaN must come out equal,
+    bit for bit, to the accumulate-into-zeros result - for the split (slab) and unsplit forms of both wgrad kernels incl. the
+    fused bias gradient, the atomic fallback, the column sums and the norm-affine gradients."""
+    old = ops.SPLITK_WS
+    ops.SPLITK_WS = torch.empty(24 * 1024 * 1024, device=dev, dtype=torch.float32)
+    nan = float('nan')
+
+    def both(fn, *shapes):
+        outs = []
+        for ow in (0, 1):
+            bufs = [torch.full(sh, nan if ow else 0.0, device=dev) for sh in shapes]
+            ops.set_option('grad_overwrite', ow)
+            try:
+                fn(*bufs)
+            finally:
+                ops.set_option('grad_overwrite', 0)
+            torch.cuda.synchronize()
+            outs.append(bufs)
+        for a, b in zip(*outs):
+            assert torch.isfinite(b).all()
+            assert torch.equal(a, b)
+
+    try:
+        # wgrad: v2 split (slabs), v2 unsplit (1280 x 11520: 240 tiles), v1 small, v1 split (conv_in-like), generic gather
+        for (B, H, Wd, C, Co, ks) in ((16, 32, 32, 320, 320, 1), (4, 8, 8, 1280, 1280, 3), (2, 12, 12, 64, 72, 3), (64, 32, 32, 8, 320, 3),
+                                      (2, 10, 10, 320, 640, 3)):
+            M = B * H * Wd
+            dy = rnd(M, Co, dev=dev, seed=1, scale=0.1).to(BF); x = rnd(M, C, dev=dev, seed=2).to(BF)
+            g = ops.Geom.linear(M) if ks == 1 else ops.Geom.conv(B, H, Wd)
+            sc = torch.empty(max(256 * Co * 2, 4096), device=dev)
+            both(lambda dW, db: ops.gemm_tn_wgrad(dy, x, dW, g, dbias=db, scratch=sc), (Co, ks * ks * C), (Co,))
+        ws, ops.SPLITK_WS = ops.SPLITK_WS, None      # atomic fallback: the entry point zeroes first
+        M = 65536
+        dy = rnd(M, 320, dev=dev, seed=1, scale=0.1).to(BF); x = rnd(M, 640, dev=dev, seed=2).to(BF)
+        dW = torch.full((320, 640), nan, device=dev); db = torch.full((320,), nan, device=dev)
+        ops.set_option('grad_overwrite', 1)
+        try:
+            ops.gemm_tn_wgrad(dy, x, dW, ops.Geom.linear(M), dbias=db, scratch=torch.empty(256 * 320 * 2, device=dev))
+        finally:
+            ops.set_option('grad_overwrite', 0)
+        check(dW, dy.float().t() @ x.float(), tol=2e-3, what='overwrite + atomics')
+        check(db, dy.float().sum(0), tol=1e-4, what='overwrite + atomics bias')
+        ops.SPLITK_WS = ws
+        # column sums
+        Bc, HW, C = 3, 200, 328
+        xx = rnd(Bc * HW, C, dev=dev, seed=1).to(BF)
+        scr = torch.empty(max(256 * C * 2, ops.norm_scratch_floats(Bc, HW, C)), device=dev)
+        both(lambda o: ops.colsum_accum(xx, o, scr), (C,))
+        per = torch.zeros(Bc, C, device=dev, dtype=BF)
+        both(lambda d: ops.image_colsum(xx, per, d, scr, Bc, HW), (C,))
+        # norm-affine gradients
+        Bn, HWn, Cn, G = 2, 100, 320, 32
+        xg = rnd(Bn * HWn, Cn, dev=dev, seed=3).to(BF); dyg = rnd(Bn * HWn, Cn, dev=dev, seed=4).to(BF)
+        gam, bet = rnd(Cn, dev=dev, seed=5), rnd(Cn, dev=dev, seed=6)
+        y = torch.empty_like(xg); st = torch.empty(Bn * G * 2, device=dev); ss = torch.empty(Bn * Cn * 2, device=dev)
+        scn = torch.empty(ops.norm_scratch_floats(Bn, HWn, Cn), device=dev)
+        ops.groupnorm_fwd(xg, y, gam, bet, st, ss, scn, Bn, HWn, Cn, G, 1e-5, 1)
+        dx = torch.empty_like(xg); coef = torch.empty(Bn * G * 2, device=dev)
+        both(lambda dg, dbb: ops.groupnorm_bwd(xg, dyg, None, dx, gam, bet, st, dg, dbb, coef, scn, Bn, HWn, Cn, G, 1), (Cn,), (Cn,))
+        stl = torch.empty(2 * Bn * HWn, device=dev); yl = torch.empty_like(xg)
+        ops.layernorm_fwd(xg, yl, gam, bet, stl)
+        scl = torch.empty(1024 * Cn * 2, device=dev)
+        both(lambda dg, dbb: ops.layernorm_bwd(xg, dyg, None, dx, gam, stl, dg, dbb, scl), (Cn,), (Cn,))
+    finally:
+        ops.SPLITK_WS = old
+        ops.set_option('grad_overwrite', 0)
+
+
+def test_reserve_cus_resizes_one_round_grids_only(ops, dev):
+    """da_set_option("reserve_cus", R): grids sized to one round of the chip use #CUs - R.  A GEMM's result does not depend
+    on how its tiles are walked (bit-identical); a weight gradient re-splits its pixel range (another fixed summation order:
+    equal to rounding, and reproducible)."""
+    M, N, K = 65536, 640, 640
+    A = rnd(M, K, dev=dev, seed=1).to(BF); W = rnd(N, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
+    bias = rnd(N, dev=dev, seed=3); R = rnd(M, N, dev=dev, seed=4).to(BF)
+    dy = rnd(M, N, dev=dev, seed=5, scale=0.1).to(BF)
+    old = ops.SPLITK_WS
+    ops.SPLITK_WS = torch.empty(24 * 1024 * 1024, device=dev, dtype=torch.float32)
+    try:
+        res = {}
+        for r in (0, 16, 16):
+            ops.set_option('reserve_cus', r)
+            out = torch.empty(M, N, device=dev, dtype=BF)
+            ops.gemm_nt(A, W, out, ops.Geom.linear(M), bias=bias, residual=R)
+            dW = torch.zeros(N, K, device=dev)
+            ops.gemm_tn_wgrad(dy, A, dW, ops.Geom.linear(M))
+            res.setdefault(r, []).append((out, dW))
+        assert torch.equal(res[0][0][0], res[16][0][0])
+        assert torch.equal(res[16][0][1], res[16][1][1])
+        check(res[16][0][1], res[0][0][1], tol=1e-5, what='wgrad under reserve_cus')
+        with pytest.raises(RuntimeError):
+            ops.set_option('reserve_cus', 500)
+    finally:
+        ops.set_option('reserve_cus', 0)
+        ops.SPLITK_WS = old
