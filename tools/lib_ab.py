@@ -9,6 +9,7 @@ With candidates, each is timed against <old.so>; without, the shipped library is
 <old.so> is any earlier build, e.g.  git show <rev>:diffusion_amd/csrc/attention.hip > /tmp/a.hip ; hipcc ... -o tools/_ab/old.so
 (built .so files are git-ignored but travel to the GPU box)."""
 import ctypes as C
+import ctypes as _ct
 import os
 import sys
 
@@ -59,6 +60,12 @@ def main():
 
 
 def run(old, new, what):
+    # DA_AB_OLD_OPTS="key=val,key=val": da_set_option calls applied to <old.so> only (each .so has its own option globals),
+    # so a copy of the shipped library with an option flipped can serve as the baseline of a run-time switch
+    for kv in filter(None, os.environ.get('DA_AB_OLD_OPTS', '').split(',')):
+        k_, v_ = kv.split('=')
+        old.da_set_option.argtypes = [_ct.c_char_p, _ct.c_int]
+        assert old.da_set_option(k_.encode(), int(v_)) == 0, kv
     dev = torch.device('cuda')
     BF = torch.bfloat16
     st = torch.cuda.current_stream().cuda_stream
@@ -99,7 +106,7 @@ def run(old, new, what):
         ws = torch.empty(32 * 1024 * 1024, device=dev)
         # (M-per-image, N, Cin, H, W, ksize): linears, GEGLU projections, convs of the three levels
         shapes = [(1024, 320, 320, 1, 1, 1), (256, 640, 640, 1, 1, 1), (64, 1280, 1280, 1, 1, 1), (1024, 960, 320, 1, 1, 1),
-                  (1024, 2560, 320, 1, 1, 1), (1024, 320, 1280, 1, 1, 1), (256, 5120, 640, 1, 1, 1), (64, 10240, 1280, 1, 1, 1),
+                  (1024, 2560, 320, 1, 1, 1), (1024, 320, 1280, 1, 1, 1), (256, 5120, 640, 1, 1, 1), (256, 1920, 640, 1, 1, 1), (256, 640, 2560, 1, 1, 1), (64, 10240, 1280, 1, 1, 1),
                   (1024, 320, 320, 32, 32, 3), (256, 640, 640, 16, 16, 3), (64, 1280, 1280, 8, 8, 3), (16, 1280, 1280, 4, 4, 3),
                   (1024, 320, 640, 32, 32, 3), (64, 1280, 2560, 8, 8, 3)]
         for hw, N, Cin, H, W, ks in shapes:
