@@ -33,8 +33,8 @@ sys.path.insert(0, os.path.dirname(__file__))
 
 # Every bound is <= 2 x the worst margin measured over the four cases on MI355X (profiles/r03_parity_margins.json; the path is
 # deterministic - fixed-order reductions everywhere - so the margins repeat run to run):
-#   measured worst:  prediction rel-L2 1.05e-2 . |loss - oracle| 2.4e-4 . per-tensor gradient-norm ratio 0.9953 .. 1.0039
-#                    whole-gradient norm ratio 1.00029 . per-slice cosine 0.99808 . rel-L2 over the stored slices 4.5e-3
+#   measured worst (s32 / s64 / s96):  prediction rel-L2 1.05e-2 . |loss - oracle| 1.6e-4 . per-tensor gradient-norm ratio
+#                    0.9953 .. 1.0039 . whole-gradient norm ratio 1.00029 . per-slice cosine 0.99852 . rel-L2 over slices 4.1e-3
 TOL = {
     'pred_rel': 2e-2,          # prediction rel-L2 (bf16 activations through ~60 layers)
     'loss_abs': 5e-4,          # |loss - oracle|: a difference of O(1) numbers at bf16 noise level (BASELINE.json asks for 1e-3)
@@ -43,12 +43,16 @@ TOL = {
     'slice_cos': 0.9962,       # per-slice cosine (matrices)
     'slice_rel': 9e-3,         # global rel-L2 over the stored gradient slices
 }
+# cfg 3 is ONE image through random-init encoders: its margins move more from build to build (|loss - oracle| 2.4e-5 ... 2.7e-4,
+# worst slice cosine 0.99698 ... 0.99828 over this round's builds; for a fixed build they repeat bit for bit) - own bounds,
+# still <= 2 x the worst measured
+TOL_CFG3 = dict(TOL, loss_abs=5.4e-4, slice_cos=0.994, slice_rel=9e-3)
 
 
-def _record(case, **kv):
+def _record(case, tol=None, **kv):
     """Keep the measured margins of a case (tests/parity_margins.py; DA_PARITY_MARGINS=<path> writes them as JSON)."""
     from parity_margins import record
-    record(case, tolerances=TOL, **kv)
+    record(case, tolerances=tol or TOL, **kv)
 
 
 def _rel(a, b):
@@ -208,13 +212,13 @@ def _full_pipeline_body(O, sd, model, dev, G):
             if c < worst_cos[1]:
                 worst_cos = (k, c)
     srel = math.sqrt(num / den)
-    _record('cfg3_256px_online_encode', pred_rel_l2=e, loss_abs_delta=dl, loss=float(loss.item()),
+    _record('cfg3_256px_online_encode', TOL_CFG3, pred_rel_l2=e, loss_abs_delta=dl, loss=float(loss.item()),
             loss_oracle=float(fx['loss']), worst_slice_cosine=worst_cos[1], worst_slice_tensor=worst_cos[0],
             slices_rel_l2=srel)
-    assert e < TOL['pred_rel'], e
-    assert dl < TOL['loss_abs'], (loss.item(), float(fx['loss']))
-    assert worst_cos[1] >= TOL['slice_cos'], worst_cos
-    assert srel < TOL['slice_rel'], srel
+    assert e < TOL_CFG3['pred_rel'], e
+    assert dl < TOL_CFG3['loss_abs'], (loss.item(), float(fx['loss']))
+    assert worst_cos[1] >= TOL_CFG3['slice_cos'], worst_cos
+    assert srel < TOL_CFG3['slice_rel'], srel
     assert all(not p.requires_grad for p in model.vae.parameters())
 
 
