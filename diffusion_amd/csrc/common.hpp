@@ -88,11 +88,16 @@ DEVINL float wave_max(float v) {
   return v;
 }
 
-DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// sigmoid through v_exp_f32 + v_rcp_f32 (1 ulp each): the IEEE division behind `1.0f / (...)` is ~10 VALU instructions, and
+// the GroupNorm-backward statistics pass (chan_reduce<1>: one silu' per element read) was bound by VALU issue, not HBM
+DEVINL float sigmoid_f(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+DEVINL float silu_f(float x) { return x * sigmoid_f(x); }
 // d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
 DEVINL float dsilu_f(float x) {
-  float s = 1.0f / (1.0f + __expf(-x));
-  return s * (1.0f + x * (1.0f - s));
+  const float s = sigmoid_f(x);
+  return s * fmaf(x, 1.0f - s, 1.0f);
 }
 // erf-GELU (diffusers GEGLU uses F.gelu, approximate='none').  erf through Abramowitz-Stegun 7.1.26, branch-free:
 //   erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2),  t = 1 / (1 + p z),  z >= 0          |error| <= 1.5e-7

@@ -44,16 +44,19 @@ __global__ void chan_reduce_kernel(ChanReduceParams p) {
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  float mu[8], rs[8], ga[8], be[8];
+  // MODE 1: per-channel folded coefficients - xhat = x*rs + nm, z = x*za + zb (two FMAs per element instead of four ops;
+  // with the silu' this pass is bound by VALU issue, not by HBM)
+  float rs[8], nm[8], za[8], zb[8];
   if (MODE == 1) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       int c = 8 * vec + e;
       int g = c / p.cpg;
-      mu[e] = p.mean_rstd[((long)b * p.G + g) * 2];
+      const float mu = p.mean_rstd[((long)b * p.G + g) * 2];
       rs[e] = p.mean_rstd[((long)b * p.G + g) * 2 + 1];
-      ga[e] = p.gamma[c];
-      be[e] = p.beta[c];
+      nm[e] = -mu * rs[e];
+      za[e] = rs[e] * p.gamma[c];
+      zb[e] = fmaf(nm[e], p.gamma[c], p.beta[c]);
     }
   }
   if (active) {
@@ -71,9 +74,10 @@ __global__ void chan_reduce_kernel(ChanReduceParams p) {
         bf16x8 dy = ld8(p.DY + row * p.lddy + 8 * vec);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float xh = (bf2f(x[e]) - mu[e]) * rs[e];
+          const float xf = bf2f(x[e]);
+          const float xh = fmaf(xf, rs[e], nm[e]);
           float dz = bf2f(dy[e]);
-          if (p.silu) dz *= dsilu_f(xh * ga[e] + be[e]);
+          if (p.silu) dz *= dsilu_f(fmaf(xf, za[e], zb[e]));
           s1[e] += dz;
           s2[e] += dz * xh;
         }

@@ -4,6 +4,7 @@ per cent, so numbers from different gpurun boxes are not comparable).
   python tools/lib_ab.py <old.so> attn [cand.so ...]   attention forward / backward at the U-Net's shapes
   python tools/lib_ab.py <old.so> tn [B]               weight-gradient GEMM at the U-Net's shapes (batch B, default 256)
   python tools/lib_ab.py <old.so> nt [B]               forward / dgrad GEMM (convs, linears with bias + residual, fused GEGLU)
+  python tools/lib_ab.py <old.so> gn                   GroupNorm(+SiLU) forward / backward at the U-Net's shapes
 With candidates, each is timed against <old.so>; without, the shipped library is the candidate.
 
 <old.so> is any earlier build, e.g.  git show <rev>:diffusion_amd/csrc/attention.hip > /tmp/a.hip ; hipcc ... -o tools/_ab/old.so
@@ -181,6 +182,35 @@ def run(old, new, what):
             print(f'geglu bwd M={M} C={C}: {ta:7.0f} -> {tb:7.0f} us ({fl / tb / 1e6:5.0f} TF/s, {100 * (ta / tb - 1):+5.1f} %) '
                   f'equal {torch.equal(dF[0], dF[1])}', flush=True)
             del a, w, F, G, dy, wt, dF
+    elif what == 'gn':
+        B, G = 256, 32
+        for HW, Cc in ((1024, 320), (1024, 960), (256, 640), (256, 1920), (64, 1280), (64, 2560), (16, 1280)):
+            M = B * HW
+            x = torch.randn(M, Cc, device=dev).to(BF); dy = torch.randn(M, Cc, device=dev).to(BF)
+            gamma = torch.randn(Cc, device=dev); beta = torch.randn(Cc, device=dev)
+            nsc = int(new.da_norm_scratch_floats(B, HW, Cc))
+            bufs = []
+            for _ in range(2):
+                bufs.append(dict(y=torch.empty_like(x), dx=torch.empty_like(x), mr=torch.empty(B * G * 2, device=dev),
+                                 ss=torch.empty(B * Cc * 2, device=dev), coef=torch.empty(B * G * 2, device=dev),
+                                 sc=torch.empty(nsc, device=dev), dg=torch.zeros(Cc, device=dev), db=torch.zeros(Cc, device=dev)))
+
+            def fwd(lib, b):
+                assert lib.da_groupnorm_fwd(x.data_ptr(), Cc, b['y'].data_ptr(), Cc, gamma.data_ptr(), beta.data_ptr(), b['mr'].data_ptr(),
+                                            b['ss'].data_ptr(), b['sc'].data_ptr(), B, HW, Cc, G, 1e-5, 1, st) == 0
+
+            def bwd(lib, b):
+                assert lib.da_groupnorm_bwd(x.data_ptr(), Cc, dy.data_ptr(), Cc, 0, 0, b['dx'].data_ptr(), Cc, gamma.data_ptr(), beta.data_ptr(),
+                                            b['mr'].data_ptr(), b['dg'].data_ptr(), b['db'].data_ptr(), b['coef'].data_ptr(), b['sc'].data_ptr(),
+                                            B, HW, Cc, G, 1, st) == 0
+            fa, fb = ab(lambda: fwd(old, bufs[0]), lambda: fwd(new, bufs[1]))
+            ba, bb = ab(lambda: bwd(old, bufs[0]), lambda: bwd(new, bufs[1]))
+            nb = M * Cc * 2
+            rel = lambda a, b: ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
+            print(f'gn HW={HW} C={Cc}: fwd {fa:7.1f} -> {fb:7.1f} us ({3 * nb / fb / 1e6:5.2f} TB/s, {100 * (fa / fb - 1):+5.1f} %)  '
+                  f'bwd {ba:7.1f} -> {bb:7.1f} us ({5 * nb / bb / 1e6:5.2f} TB/s, {100 * (ba / bb - 1):+5.1f} %)  '
+                  f'rel y {rel(bufs[1]["y"], bufs[0]["y"]):.1e} dx {rel(bufs[1]["dx"], bufs[0]["dx"]):.1e}', flush=True)
+            del x, dy, bufs
     else:
         raise SystemExit(__doc__)
 
