@@ -138,3 +138,61 @@ def test_reducer_single_process_is_noop():
     red.begin(); red.ready(512); red.ready(0); red.flush()
     assert not red.enabled and torch.equal(flat, torch.arange(1000, dtype=torch.float32))
     assert sum(b - a for a, b in red.launched) == 1000
+
+
+def _reserve_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from diffusion_amd import ops
+    from diffusion_amd.parallel import BucketedAllReducer
+    calls = []
+    real = ops.set_option
+
+    def spy(key, value):          # the C library's option is process-wide: record what the reducer asks for, then forward
+        calls.append((key, int(value)))
+        real(key, value)
+
+    ops.set_option = spy
+    flat = torch.randn(6000, generator=torch.Generator().manual_seed(rank))
+    steps_ok = True
+    for overlap in (True, False):
+        red = BucketedAllReducer(flat, bucket_elems=1000, align=64, overlap=overlap)
+        red.reserve_cus = 8
+        red.on_bucket = lambda lo, hi: calls.append(('bucket', lo))   # per-bucket continuation (AdamW slice in the trainer)
+        for _ in range(2):                                          # two optimizer steps
+            n0 = len(calls)
+            red.begin()
+            for lo in (5000, 3900, 2000, 900):
+                red.ready(lo)
+            mid = list(calls[n0:])
+            red.flush()
+            seq = calls[n0:]
+            if overlap:   # reserve set once, when the first bucket leaves; cleared in flush(); buckets in between
+                steps_ok &= seq[0] == ('reserve_cus', 8) and seq[-1] == ('reserve_cus', 0)
+                steps_ok &= [c for c in seq if c[0] == 'reserve_cus'] == [('reserve_cus', 8), ('reserve_cus', 0)]
+                steps_ok &= ('reserve_cus', 8) in mid and sum(c[0] == 'bucket' for c in seq) >= 4
+            else:         # exchange after backward: nothing overlaps, no CUs are withheld
+                steps_ok &= not any(c[0] == 'reserve_cus' for c in seq) and not mid
+            steps_ok &= not red._reserved
+    q.put((rank, steps_ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reserved_cus_are_held_only_while_buckets_are_in_flight_gloo_world2():
+    """parallel.BucketedAllReducer.reserve_cus (the trainer's DA_DP_RESERVE_CUS, default 8 when world > 1): the one-round GEMM
+    grids shrink to #CUs - R from the first bucket of a step until flush() - the part of backward that runs beside the
+    collective - and never when the exchange is not overlapped.  The option call goes through the C ABI (da_set_option is
+    host-only, so this runs without a GPU)."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reserve_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
