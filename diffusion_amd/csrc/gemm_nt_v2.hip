@@ -64,6 +64,7 @@ struct GemmNT2Params {
   int total_blocks;              // persistent (EARLY) form: tiles vblock = blockIdx.x, += gridDim.x, < total_blocks
   FastDiv div_hw, div_w;         // exact m / (Hout*Wout) and rem / Wout for m < 2^24 (persistent convolution form: a runtime
                                  // divisor's reciprocal would live in a VGPR across the tile walk)
+  FastDiv div_nblk, div_tn;      // the same for the tile walk's own divisions (block -> split, tile row)
   int korder;                    // 3x3 K-loop order: 0 = tap-major (k = tap*Cin + c, as W is laid out), 1 = channel-chunk-major
                                  // with the 9 taps innermost (see the K-loop comment)
 };
@@ -184,12 +185,12 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   const int nblk = p.tiles_m * p.tiles_n;
   int split, tn, m0, n0;  // the tile the DMA descriptors below belong to (wave-uniform)
   auto locate = [&](int vb) {
-    split = vb / nblk;  // splits of a tile are nblk workgroups apart
+    split = PERSIST ? (int)fdiv((unsigned)vb, p.div_nblk) : vb / nblk;  // splits of a tile are nblk workgroups apart
     int bid = vb - split * nblk;
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tm = bid / p.tiles_n;
+    const int tm = PERSIST ? (int)fdiv((unsigned)bid, p.div_tn) : bid / p.tiles_n;
     tn = bid - tm * p.tiles_n;
     m0 = tm * V2_BM;
     n0 = tn * BN;
@@ -202,8 +203,13 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   const int HWo = p.Hout * p.Wout;
   // mode 4: stride 2 with zero padding at the bottom / right only (the VAE encoder's downsampler) = mode 1 without the
   // one-pixel shift
-  const int pad = (p.ksize == 3 && p.mode != 4) ? 1 : 0;
-  const int gmul = (p.mode == 1 || p.mode == 4) ? 2 : 1, gshift = (p.mode == 2 || p.mode == 3) ? 1 : 0, pmask = (p.mode == 2) ? 1 : 0;
+  // PCONV: the persistent convolution form is dispatched for stride-1 3x3 gathers only (mode 0: every multi-round conv and
+  // conv dgrad of the U-Net) - its gather constants are compile-time, which keeps the tile walk free of the uniform-value
+  // VGPRs (shift amounts, limits) the compiler otherwise carried - and spilled - across the K loop
+  constexpr bool PCONV = PERSIST && !EARLY;
+  const int pad = PCONV ? 1 : ((p.ksize == 3 && p.mode != 4) ? 1 : 0);
+  const int gmul = PCONV ? 1 : ((p.mode == 1 || p.mode == 4) ? 2 : 1), gshift = PCONV ? 0 : ((p.mode == 2 || p.mode == 3) ? 1 : 0),
+            pmask = PCONV ? 0 : ((p.mode == 2) ? 1 : 0);
   const int hlim = gshift ? 2 * p.Hin : p.Hin, wlim = gshift ? 2 * p.Win : p.Win;
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   // bias for this column block -> LDS (behind the stage buffers), read back in the epilogue; zeros when absent
@@ -223,7 +229,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   //   amask[j]  bit t: tap t reads inside the image (modes: 0 stride 1, 1 stride 2, 2 dgrad of stride 2, 3 fused
   //             nearest-2x upsample); bits 16/17: parity of the output row / column (mode 3 only)
   // so that a step adds one wave-uniform offset (tap displacement + channel offset) and selects the zero page.
-  const int ntaps = p.ksize * p.ksize;
+  const int ntaps = PCONV ? 9 : p.ksize * p.ksize;
   const bf16* abase[AJ];
   unsigned amask[AJ];
   unsigned aoff[AJ];  // EARLY forms, and the persistent convolution form (packed descriptors)
@@ -261,7 +267,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
     const int ow = rem - oh * p.Wout;
     unsigned mask = ((oh & 1) << 16) | ((ow & 1) << 17);
     for (int t = 0; t < ntaps; ++t) {
-      const int r = p.ksize == 3 ? t / 3 : 0, s2 = p.ksize == 3 ? t - 3 * r : 0;
+      const int r = (PCONV || p.ksize == 3) ? t / 3 : 0, s2 = (PCONV || p.ksize == 3) ? t - 3 * r : 0;
       const int th = oh * gmul + r - pad, tw = ow * gmul + s2 - pad;
       const bool ok = mval && (unsigned)th < (unsigned)hlim && (unsigned)tw < (unsigned)wlim && !((th | tw) & pmask);
       mask |= (ok ? 1u : 0u) << t;
@@ -700,7 +706,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
           }
         }
         if (p.rowbias) {
-          const int b = m / HWo;
+          const int b = PERSIST ? (int)fdiv((unsigned)m, p.div_hw) : m / HWo;
           const bf16x8 rbv = ld8(p.rowbias + (long)b * p.ldrb + n);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bf2f(rbv[e]);
@@ -846,6 +852,9 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
   p.splits = (nk_total + p.ksteps_per_split - 1) / p.ksteps_per_split;  // no empty splits
   p.slab_stride = (long)p.M * p.N;
   p.total_blocks = p.tiles_m * p.tiles_n * p.splits;
+  p.div_nblk = make_fastdiv((unsigned)(p.tiles_m * p.tiles_n));
+  p.div_tn = make_fastdiv((unsigned)p.tiles_n);
+  if (PERSIST && (p.total_blocks >= (1 << 24) || p.M >= (1 << 24))) return DA_ERR_SHAPE;  // FastDiv range
   const int grid = PERSIST ? persistent_grid(p.total_blocks) : p.total_blocks;
   if (p.splits > 1) {
     GemmNT2Params pk = p;
@@ -877,6 +886,9 @@ int launch_v2_geglu(GemmNT2Params p, hipStream_t stream) {
   static unsigned long long attr_done = 0;  // one bit per device
   if (da_ensure_dyn_smem((const void*)gemm_nt2_kernel<4, 5, 4, 4, 64, false, GM, true>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
   p.total_blocks = p.tiles_m * p.tiles_n;
+  p.div_nblk = make_fastdiv((unsigned)p.total_blocks);
+  p.div_tn = make_fastdiv((unsigned)p.tiles_n);
+  if (p.total_blocks >= (1 << 24) || p.M >= (1 << 24)) return DA_ERR_SHAPE;  // FastDiv range
   hipLaunchKernelGGL((gemm_nt2_kernel<4, 5, 4, 4, 64, false, GM, true>), dim3(persistent_grid(p.total_blocks)), dim3(1024), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
@@ -895,7 +907,8 @@ int launch_v2(const GemmNT2Params& p, int splits, float* ws, hipStream_t stream)
     // request the next tile's first K-step (and build its gather descriptors) ahead of the current tile's epilogue
     // (da_set_option("gemm_nt_persist_conv", 0) = one tile per workgroup, as before round 3)
     const long tiles = (long)((p.M + 255) / 256) * ((p.N + 319) / 320) * (splits > 1 ? splits : 1);
-    if (g_nt_persist_conv && g_nt_persist != 0 && p.ksize == 3 && tiles > da_usable_cus(256) && p.N % 320 == 0 && p.M < (1 << 24) &&
+    if (g_nt_persist_conv && g_nt_persist != 0 && p.ksize == 3 && p.mode == 0 && tiles > da_usable_cus(256) && p.N % 320 == 0 &&
+        p.M < (1 << 24) &&
         (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.lda * 2 < (1L << 32))
       return launch_v2_mode<MT, NT, WM, WN, BK, false, false, MF, true>(p, splits, ws, stream);
   }
@@ -925,6 +938,7 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
   p.total_blocks = 0;
   p.div_hw = make_fastdiv((unsigned)(Hout * Wout));
   p.div_w = make_fastdiv((unsigned)Wout);
+  p.div_nblk = p.div_tn = make_fastdiv(1u);  // set by the launcher once the tile grid is known
   if (variant == 10) return launch_v2<8, 5, 2, 4, 64>(p, splits, ws, stream);
   if (variant == 11) return launch_v2<4, 10, 2, 2, 32>(p, 1, ws, stream);  // 128 x 320 x 32, 4 waves, 2 workgroups / CU
   if (variant == 12) return launch_v2<4, 5, 4, 4, 64>(p, splits, ws, stream);  // 256 x 320 x 64, 16 waves (4 / SIMD)
@@ -952,7 +966,7 @@ extern "C" int da_gemm_nt_geglu(const void* A, long lda, const void* W, void* F,
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
   p.G = (bf16*)G; p.ldg = ldg; p.inner = inner; p.korder = 0; p.total_blocks = 0;
-  p.div_hw = p.div_w = make_fastdiv(1u);
+  p.div_hw = p.div_w = p.div_nblk = p.div_tn = make_fastdiv(1u);
   return launch_v2_geglu<1>(p, stream);
 }
 
@@ -973,6 +987,6 @@ extern "C" int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, c
   p.tiles_m = p.tiles_n = 0;
   p.splits = 1; p.ksteps_per_split = 0; p.slab_stride = 0;
   p.G = (bf16*)const_cast<void*>(F); p.ldg = ldf; p.inner = inner; p.korder = 0; p.total_blocks = 0;
-  p.div_hw = p.div_w = make_fastdiv(1u);
+  p.div_hw = p.div_w = p.div_nblk = p.div_tn = make_fastdiv(1u);
   return launch_v2_geglu<2>(p, stream);
 }
