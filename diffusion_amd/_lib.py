@@ -79,6 +79,12 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     _lib = lib
+    # DA_SET_OPTIONS="key=value,key=value": da_set_option calls applied once at load (A/B runs of whole programs: bench.py,
+    # the tests); an unknown key or rejected value is an error, not a silent default
+    for kv in filter(None, os.environ.get('DA_SET_OPTIONS', '').split(',')):
+        k, _, v = kv.partition('=')
+        if lib.da_set_option(k.strip().encode(), int(v)) != 0:
+            raise ValueError(f'DA_SET_OPTIONS: da_set_option({k.strip()!r}, {v}) was rejected')
     return lib
 
 

@@ -253,6 +253,7 @@ extern int g_nt_persist;
 extern int g_reserve_cus;
 extern int g_nt_persist_conv;
 extern int g_grad_overwrite;
+extern int g_gn_resident, g_gn_resident_form, g_gn_resident_min_slab;  // norms.hip
 int da_usable_cus(int cus);
 static int g_nt_variant = 0;
 static int g_nt_mfma32 = 0;   // da_set_option("gemm_nt_mfma32", 0 never | -1 for K <= 320 | 1 always): the 256x320 form on
@@ -372,6 +373,21 @@ extern "C" int da_set_option(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_nt_persist_conv")) {
     g_nt_persist_conv = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "gn_resident")) {
+    if (value < 0) return DA_ERR_SHAPE;
+    g_gn_resident = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "gn_resident_min_slab")) {
+    if (value < 0) return DA_ERR_SHAPE;
+    g_gn_resident_min_slab = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "gn_resident_form")) {
+    if (value < 0 || value > 2) return DA_ERR_SHAPE;
+    g_gn_resident_form = value;
     return DA_OK;
   }
   if (key && !strcmp(key, "grad_overwrite")) {

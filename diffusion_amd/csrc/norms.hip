@@ -13,6 +13,11 @@
 #include "diffusion_amd.h"
 
 extern int g_grad_overwrite;  // gemm_tn.hip: da_set_option("grad_overwrite") - write the gradient outputs instead of adding
+// da_set_option("gn_resident", n): register-resident single-pass GroupNorm where the slab fits and the launch has >= n
+// workgroups (0 = never, 1 = whenever it fits); "gn_resident_form": 0 auto | 1 16-wave forms only | 2 12-wave form above 8 vectors
+int g_gn_resident = 192;
+int g_gn_resident_form = 0;
+int g_gn_resident_min_slab = 64 * 1024;  // "gn_resident_min_slab": bytes of one tensor per workgroup below which the multi-pass form runs
 
 namespace {
 
@@ -776,6 +781,450 @@ __global__ __launch_bounds__(256) void ln_bwd5_kernel(const bf16* X, long ldx, c
   }
 }
 
+
+// ---- GroupNorm with the slab resident in registers ("single pass"): a 1024-thread workgroup owns HW pixels x CW channels
+// of ONE image (CW = whole groups, a multiple of 8), loads that slab with every 16-B load in flight at once, reduces it,
+// and rewrites it from registers - x (and dy) cross the fabric once instead of twice.  Thread t keeps chunk j = t % chunks
+// (8 channels) of pixels t / chunks + k*P, k < NL.  The arithmetic runs channel-outer / pixel-inner so that only one
+// channel's coefficients and accumulators are live beside the NL (forward) or 2*NL (backward) data vectors: the backward
+// form must fit 2 x 11 vectors + everything else in the 128 VGPRs a 16-wave workgroup gets.
+// The parts of one image sit 8 workgroup ids apart (same XCD): when CW*2 bytes is not a multiple of the 128-B line
+// (320 channels = 32 groups of 10) neighbouring parts share lines, and the shared lines are then served by one L2.
+// Measured (tools/slab_pass.hip, 256 x 1024 px x 320 ch): forward 2 x 160 channels 5.6 TB/s of useful bytes, backward
+// 4 x 80 channels 3.9 TB/s (160-B segments; 3.1 without the XCD placement), line-aligned shapes 5.8-6.2 TB/s.
+struct GnResParams {
+  const bf16* X; const bf16* DY; const bf16* Radd; bf16* OUT;
+  const float* gamma; const float* beta;
+  float* mean_rstd;   // [B][G][2]: written by the forward, read by the backward
+  float* partial;     // backward: [B][C][2] per-image channel sums (dz, dz*xhat) for dbeta / dgamma
+  long ldx, lddy, ldr, ldo;
+  int HW, C, G, cpg, CW, chunks, P, parts, peers8, silu, nseg;
+  float eps, inv_n;
+};
+
+// data vectors are kept as four 32-bit words (two bf16 each) and updated a word at a time, so that the compiler never holds
+// a half-built vector as eight separate values
+DEVINL u32x4 ldnt8w(const bf16* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+DEVINL void st8w(bf16* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+DEVINL u32x4 ldnt8o(const bf16* base, unsigned byte_off) {   // uniform base + 32-bit lane offset (saddr form)
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+DEVINL void st8o(bf16* base, unsigned byte_off, u32x4 v) {
+  *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+DEVINL u32x4 sel8(bool ok, u32x4 v) {
+  u32x4 r;
+  r[0] = ok ? v[0] : 0u; r[1] = ok ? v[1] : 0u; r[2] = ok ? v[2] : 0u; r[3] = ok ? v[3] : 0u;
+  return r;
+}
+DEVINL float bflo(unsigned w) { return __uint_as_float(w << 16); }
+DEVINL float bfhi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+DEVINL unsigned bfpack(float lo, float hi) {
+  bf16x2 v;
+  v[0] = f2bf(lo);
+  v[1] = f2bf(hi);
+  return __builtin_bit_cast(unsigned, v);
+}
+
+DEVINL void gn_res_block(const GnResParams& p, int& img, int& part) {
+  const int id = blockIdx.x;
+  if (p.peers8) {
+    const int span = 8 * p.parts;
+    const int g = id / span, r = id - g * span;
+    part = r >> 3;
+    img = g * 8 + (r & 7);
+  } else {
+    img = id / p.parts;
+    part = id - img * p.parts;
+  }
+}
+
+// red[P][CW] float2 per-(pixel lane, channel) -> chs[CW] float2 per channel; fixed order.  Returns with chs valid.
+DEVINL void gn_res_reduce(const GnResParams& p, const float2* red, float2* red2, float2* chs) {
+  const int t = threadIdx.x, T = blockDim.x;
+  __syncthreads();
+  const int rows = p.P < p.HW ? p.P : p.HW;   // pixel lanes beyond HW only hold zeros
+  for (int idx = t; idx < p.nseg * p.CW; idx += T) {
+    const int seg = idx / p.CW, c = idx - seg * p.CW;
+    float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
+    int k = seg;
+    for (; k + p.nseg < rows; k += 2 * p.nseg) {
+      const float2 v0 = red[(long)k * p.CW + c], v1 = red[(long)(k + p.nseg) * p.CW + c];
+      a0 += v0.x; q0 += v0.y;
+      a1 += v1.x; q1 += v1.y;
+    }
+    if (k < rows) {
+      const float2 v0 = red[(long)k * p.CW + c];
+      a0 += v0.x; q0 += v0.y;
+    }
+    red2[idx] = make_float2(a0 + a1, q0 + q1);
+  }
+  __syncthreads();
+  for (int c = t; c < p.CW; c += T) {
+    float a = 0.f, q = 0.f;
+    for (int sgi = 0; sgi < p.nseg; ++sgi) {
+      const float2 v = red2[sgi * p.CW + c];
+      a += v.x; q += v.y;
+    }
+    chs[c] = make_float2(a, q);
+  }
+  __syncthreads();
+}
+
+// LDS floats: red 2*(P+1)*CW | red2 2*nseg*CW | chs 2*CW | cf 4*CW | gs 4*(CW/cpg)
+static inline size_t gn_res_lds_floats(int P, int CW, int nseg, int cpg) {
+  return (size_t)2 * (P + 1) * CW + (size_t)2 * nseg * CW + 2 * CW + 4 * CW + 4 * (CW / cpg);
+}
+
+template <int NL, bool SILU>
+__global__ __launch_bounds__(1024) void gn_res_fwd_kernel(GnResParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* red = reinterpret_cast<float2*>(smem);
+  float2* red2 = red + (long)(p.P + 1) * p.CW;   // row P: where idle pixel lanes dump their (zero) sums
+  float2* chs = red2 + (long)p.nseg * p.CW;
+  float2* cf = chs + p.CW;                       // per channel (scale, shift)
+  float2* gs = cf + 2 * p.CW;                    // per group (mean, rstd)
+  int img, part;
+  gn_res_block(p, img, part);
+  const int t = threadIdx.x, j = t % p.chunks, p0 = t / p.chunks;
+  const bool live = p0 < p.P;
+  const int c0 = part * p.CW;
+  // every lane loads (rows beyond the slab re-read its last row and are zeroed): no branches around the loads, one 32-bit
+  // offset per vector from a uniform base
+  const bf16* xb = p.X + (long)img * p.HW * p.ldx + c0;
+  const int pl = live ? p0 : p.P - 1;
+  const int pl0 = live ? p0 : p.P;
+  u32x4 a[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int pix = pl + k * p.P;
+    const int pc = pix < p.HW ? pix : p.HW - 1;
+    a[k] = ldnt8o(xb, (unsigned)(pc * (int)p.ldx + 8 * j) * 2u);
+  }
+#pragma unroll
+  for (int k = 0; k < NL; ++k) a[k] = sel8(live && pl + k * p.P < p.HW, a[k]);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    float s1 = 0.f, s2 = 0.f, u1 = 0.f, u2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const float v0 = bflo(a[k][w]), v1 = bfhi(a[k][w]);
+      s1 += v0;
+      s2 = fmaf(v0, v0, s2);
+      u1 += v1;
+      u2 = fmaf(v1, v1, u2);
+    }
+    red[pl0 * p.CW + 8 * j + 2 * w] = make_float2(s1, s2);       // unconditional: a branch here lets the compiler sink and
+    red[pl0 * p.CW + 8 * j + 2 * w + 1] = make_float2(u1, u2);   // interleave the whole sweep (registers)
+  }
+  gn_res_reduce(p, red, red2, chs);
+#pragma unroll
+  for (int k = 0; k < NL; ++k) reg_tie(a[k]);   // the second sweep re-reads the packed values: nothing converted is kept across
+  const int ng = p.CW / p.cpg, g0 = c0 / p.cpg;
+  for (int gl = t; gl < ng; gl += blockDim.x) {
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < p.cpg; ++i) {
+      const float2 v = chs[gl * p.cpg + i];
+      s += v.x; q += v.y;
+    }
+    const float mean = s * p.inv_n;
+    const float var = fmaxf(q * p.inv_n - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + p.eps);
+    gs[gl] = make_float2(mean, rstd);
+    p.mean_rstd[((long)img * p.G + g0 + gl) * 2] = mean;
+    p.mean_rstd[((long)img * p.G + g0 + gl) * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  for (int c = t; c < p.CW; c += blockDim.x) {
+    const float2 g = gs[c / p.cpg];
+    const float sc = g.y * p.gamma[c0 + c];
+    cf[c] = make_float2(sc, p.beta[c0 + c] - g.x * sc);
+  }
+  __syncthreads();
+  if (!live) return;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float2 f0 = cf[8 * j + 2 * w], f1 = cf[8 * j + 2 * w + 1];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      float z0 = fmaf(bflo(a[k][w]), f0.x, f0.y), z1 = fmaf(bfhi(a[k][w]), f1.x, f1.y);
+      if (SILU) {
+        z0 = silu_f(z0);
+        z1 = silu_f(z1);
+      }
+      a[k][w] = bfpack(z0, z1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  bf16* yb = p.OUT + (long)img * p.HW * p.ldo + c0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int pix = p0 + k * p.P;
+    if (pix < p.HW) st8o(yb, (unsigned)(pix * (int)p.ldo + 8 * j) * 2u, a[k]);
+  }
+}
+
+// backward: dx = dz*sc + x*Q + R (+ Radd), dz = dy*silu'(x*sc+sh);  per group c1 = mean(gamma*dz), c2 = mean(gamma*dz*xhat),
+// Q = -rstd^2*c2, R = -rstd*c1 + mean*rstd^2*c2 (as gn_apply2_kernel<true>).  dz is recomputed in the second sweep rather
+// than kept (no registers for it); Radd lands in the dy registers once they are dead and is added to the bf16-rounded dx.
+template <int NL, bool SILU, int T>
+__global__ __launch_bounds__(T) void gn_res_bwd_kernel(GnResParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* red = reinterpret_cast<float2*>(smem);
+  float2* red2 = red + (long)(p.P + 1) * p.CW;   // row P: where idle pixel lanes dump their (zero) sums
+  float2* chs = red2 + (long)p.nseg * p.CW;
+  float4* cf = reinterpret_cast<float4*>(chs + p.CW);   // per channel (rstd, -mean*rstd, rstd*gamma, shift)
+  float4* gs = cf + p.CW;                                // per group (mean, rstd, Q, R)
+  int img, part;
+  gn_res_block(p, img, part);
+  const int t = threadIdx.x, j = t % p.chunks, p0 = t / p.chunks;
+  const bool live = p0 < p.P;
+  const int c0 = part * p.CW;
+  const bf16* xb = p.X + (long)img * p.HW * p.ldx + c0;
+  const bf16* dyb = p.DY + (long)img * p.HW * p.lddy + c0;
+  const int pl = live ? p0 : p.P - 1;
+  const int pl0 = live ? p0 : p.P;
+  unsigned a[NL][4], b[NL][4];   // plain words, not vectors: each is rewritten on its own (dz over dy, dx over x)
+  {
+    u32x4 va[NL], vb[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int pix = pl + k * p.P;
+      const int pc = pix < p.HW ? pix : p.HW - 1;
+      va[k] = ldnt8o(xb, (unsigned)(pc * (int)p.ldx + 8 * j) * 2u);
+      vb[k] = ldnt8o(dyb, (unsigned)(pc * (int)p.lddy + 8 * j) * 2u);
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const bool ok = live && pl + k * p.P < p.HW;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a[k][w] = ok ? va[k][w] : 0u;
+        b[k][w] = ok ? vb[k][w] : 0u;
+        reg_tie(b[k][w]);   // materialise now: a select sunk to its use keeps the whole loaded tuple alive beside the new words
+      }
+    }
+  }
+  for (int c = t; c < p.CW; c += blockDim.x) {
+    const int g = (c0 + c) / p.cpg;
+    const float mu = p.mean_rstd[((long)img * p.G + g) * 2], rs = p.mean_rstd[((long)img * p.G + g) * 2 + 1];
+    const float nm = -mu * rs, ga = p.gamma[c0 + c];
+    cf[c] = make_float4(rs, nm, rs * ga, fmaf(nm, ga, p.beta[c0 + c]));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float4 f0 = cf[8 * j + 2 * w], f1 = cf[8 * j + 2 * w + 1];
+    float s1 = 0.f, s2 = 0.f, u1 = 0.f, u2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const float x0 = bflo(a[k][w]), x1 = bfhi(a[k][w]);
+      float d0 = bflo(b[k][w]), d1 = bfhi(b[k][w]);
+      if (SILU) {   // dz replaces dy in its registers, rounded to bf16 (what a separate SiLU backward would hand to GroupNorm):
+        d0 *= dsilu_f(fmaf(x0, f0.z, f0.w));   // the second sweep then needs no second exp / rcp per element
+        d1 *= dsilu_f(fmaf(x1, f1.z, f1.w));
+        unsigned pk = bfpack(d0, d1);
+        reg_tie(pk);   // pack HERE: left alone, the compiler keeps both floats of every element until the second sweep
+        b[k][w] = pk;
+      }
+      s1 += d0;
+      s2 = fmaf(d0, fmaf(x0, f0.x, f0.y), s2);
+      u1 += d1;
+      u2 = fmaf(d1, fmaf(x1, f1.x, f1.y), u2);
+      if (SILU) __builtin_amdgcn_sched_barrier(0);   // bound the transcendental chains in flight (registers)
+    }
+    red[pl0 * p.CW + 8 * j + 2 * w] = make_float2(s1, s2);       // unconditional: a branch here lets the compiler sink and
+    red[pl0 * p.CW + 8 * j + 2 * w + 1] = make_float2(u1, u2);   // interleave the whole sweep (registers)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  gn_res_reduce(p, red, red2, chs);
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {   // the second sweep recomputes dz from the packed values instead of keeping 8*NL floats
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      reg_tie(a[k][w]);
+      reg_tie(b[k][w]);
+    }
+  }
+  int j2 = j, q0 = p0;   // ... and the store / Radd offsets are derived after this point, not carried through the first sweep
+  reg_tie(j2);
+  reg_tie(q0);
+  for (int c = t; c < p.CW; c += blockDim.x) {
+    const float2 v = chs[c];
+    p.partial[((long)img * p.C + c0 + c) * 2] = v.x;
+    p.partial[((long)img * p.C + c0 + c) * 2 + 1] = v.y;
+  }
+  const int ng = p.CW / p.cpg, g0 = c0 / p.cpg;
+  for (int gl = t; gl < ng; gl += blockDim.x) {
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < p.cpg; ++i) {
+      const float2 v = chs[gl * p.cpg + i];
+      const float ga = p.gamma[c0 + gl * p.cpg + i];
+      s = fmaf(v.x, ga, s);
+      q = fmaf(v.y, ga, q);
+    }
+    const float c1 = s * p.inv_n, c2 = q * p.inv_n;
+    const float mu = p.mean_rstd[((long)img * p.G + g0 + gl) * 2], rs = p.mean_rstd[((long)img * p.G + g0 + gl) * 2 + 1];
+    gs[gl] = make_float4(mu, rs, -rs * rs * c2, -rs * c1 + mu * rs * rs * c2);
+  }
+  __syncthreads();
+  if (!live) return;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float4 f0 = cf[8 * j2 + 2 * w], f1 = cf[8 * j2 + 2 * w + 1];
+    const float4 g0q = gs[(8 * j2 + 2 * w) / p.cpg], g1q = gs[(8 * j2 + 2 * w + 1) / p.cpg];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const float x0 = bflo(a[k][w]), x1 = bfhi(a[k][w]);
+      const float d0 = bflo(b[k][w]), d1 = bfhi(b[k][w]);
+      a[k][w] = bfpack(fmaf(d0, f0.z, fmaf(x0, g0q.z, g0q.w)), fmaf(d1, f1.z, fmaf(x1, g1q.z, g1q.w)));
+      if (SILU) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  bf16* ob = p.OUT + (long)img * p.HW * p.ldo + c0;
+  if (p.Radd) {
+    const bf16* rb = p.Radd + (long)img * p.HW * p.ldr + c0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int pix = q0 + k * p.P;
+      const int pc = pix < p.HW ? pix : p.HW - 1;
+      const u32x4 v = ldnt8o(rb, (unsigned)(pc * (int)p.ldr + 8 * j2) * 2u);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) b[k][w] = v[w];
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k)
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        a[k][w] = bfpack(bflo(a[k][w]) + bflo(b[k][w]), bfhi(a[k][w]) + bfhi(b[k][w]));
+  }
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int pix = q0 + k * p.P;
+    if (pix < p.HW) st8o(ob, (unsigned)(pix * (int)p.ldo + 8 * j2) * 2u, u32x4{a[k][0], a[k][1], a[k][2], a[k][3]});
+  }
+}
+
+// Slab geometry for (B, HW, C, G): CW = whole groups, whole 16-B vectors, NL data vectors per thread <= max_nl.
+// Prefers line-aligned segments, then the widest part that still gives every CU a workgroup.  false -> no fit (the
+// multi-pass kernels take the call).
+bool gn_res_plan(int B, int HW, int C, int G, long ld_min, long ld_max, bool bwd, GnResParams& p, int& nl, int& threads) {
+  const int cpg = C / G;
+  int unit = cpg;
+  while (unit & 7) unit += cpg;                 // lcm(cpg, 8)
+  if (unit > C || (C % unit)) return false;
+  if ((long)HW * ld_max * 2 >= (1L << 31)) return false;   // 32-bit byte offsets inside an image
+  // forward: 1024 threads, <= 21 vectors each.  backward (two resident tensors): 1024 threads x <= 8 vectors, or 768
+  // threads (168 VGPRs) x <= 14
+  const int nT = (bwd && g_gn_resident_form != 1) ? 2 : 1;
+  const int Ts[2] = {1024, 768};
+  const int maxnl[2] = {bwd ? (g_gn_resident_form == 2 ? 8 : 11) : 21, 14};
+  double best = 1e30;
+  int best_cw = 0, best_t = 0;
+  for (int ti = 0; ti < nT; ++ti) {
+    const int T = Ts[ti];
+    for (int cw = unit; cw <= C; cw += unit) {
+      if (C % cw) continue;
+      const int chunks = cw / 8;
+      if (chunks > T) break;
+      const int P = T / chunks;
+      const int n = (HW + P - 1) / P;
+      if (n > maxnl[ti]) continue;
+      const long wgs = (long)B * (C / cw);
+      if (wgs < g_gn_resident) continue;         // too few workgroups for 256 CUs: the chunked kernels spread an image wider
+      const bool aligned = ((cw * 2) % 128 == 0) && ((ld_min * 2) % 128 == 0);
+      double cost = aligned ? 1.0 : (double)(cw * 2 + 128) / (double)(cw * 2);   // expected line over-fetch
+      if (cost > 1.85) continue;                  // 80-B segments and narrower fetch more than the extra passes they save
+      // ties: the widest slab (a workgroup's load -> reduce -> store chain is serial; 40-KB slabs measured 0.4-0.9x of the
+      // multi-pass kernels, 160-KB ones 1.2-1.7x), the 16-wave form
+      if ((long)HW * cw * 2 < g_gn_resident_min_slab) continue;
+      if (gn_res_lds_floats(P, cw, T / cw < 1 ? 1 : T / cw, cpg) * sizeof(float) > 160 * 1024) continue;
+      cost += 0.01 * ti - 0.002 * n;
+      if (wgs < 256) cost += 0.05;
+      if (cost < best) { best = cost; best_cw = cw; best_t = T; }
+    }
+  }
+  if (!best_cw) return false;
+  threads = best_t;
+  p.CW = best_cw;
+  p.chunks = best_cw / 8;
+  p.P = best_t / p.chunks;
+  p.parts = C / best_cw;
+  p.peers8 = (B % 8 == 0 && p.parts > 1) ? 1 : 0;
+  p.nseg = best_t / best_cw < 1 ? 1 : best_t / best_cw;
+  nl = (HW + p.P - 1) / p.P;
+  return true;
+}
+
+template <int NL, bool SILU>
+int launch_gn_res_fwd2(const GnResParams& p, int B, hipStream_t stream) {
+  const size_t smem = gn_res_lds_floats(p.P, p.CW, p.nseg, p.cpg) * sizeof(float);
+  if (smem > 160 * 1024) return DA_ERR_SHAPE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)gn_res_fwd_kernel<NL, SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return DA_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gn_res_fwd_kernel<NL, SILU>), dim3(B * p.parts), dim3(1024), smem, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+template <int NL>
+int launch_gn_res_fwd(const GnResParams& p, int B, hipStream_t stream) {
+  return p.silu ? launch_gn_res_fwd2<NL, true>(p, B, stream) : launch_gn_res_fwd2<NL, false>(p, B, stream);
+}
+
+template <int NL, bool SILU, int T>
+int launch_gn_res_bwd2(const GnResParams& p, int B, hipStream_t stream) {
+  const size_t smem = gn_res_lds_floats(p.P, p.CW, p.nseg, p.cpg) * sizeof(float);
+  if (smem > 160 * 1024) return DA_ERR_SHAPE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)gn_res_bwd_kernel<NL, SILU, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return DA_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gn_res_bwd_kernel<NL, SILU, T>), dim3(B * p.parts), dim3(T), smem, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+template <int NL, int T>
+int launch_gn_res_bwd(const GnResParams& p, int B, hipStream_t stream) {
+  return p.silu ? launch_gn_res_bwd2<NL, true, T>(p, B, stream) : launch_gn_res_bwd2<NL, false, T>(p, B, stream);
+}
+
+int dispatch_gn_res_fwd(int nl, const GnResParams& p, int B, hipStream_t s) {
+  if (nl <= 1) return launch_gn_res_fwd<1>(p, B, s);
+  if (nl <= 2) return launch_gn_res_fwd<2>(p, B, s);
+  if (nl <= 3) return launch_gn_res_fwd<3>(p, B, s);
+  if (nl <= 4) return launch_gn_res_fwd<4>(p, B, s);
+  if (nl <= 6) return launch_gn_res_fwd<6>(p, B, s);
+  if (nl <= 8) return launch_gn_res_fwd<8>(p, B, s);
+  if (nl <= 11) return launch_gn_res_fwd<11>(p, B, s);
+  if (nl <= 16) return launch_gn_res_fwd<16>(p, B, s);
+  return launch_gn_res_fwd<21>(p, B, s);
+}
+
+int dispatch_gn_res_bwd(int nl, int threads, const GnResParams& p, int B, hipStream_t s) {
+  if (threads == 768) {
+    if (nl <= 11) return launch_gn_res_bwd<11, 768>(p, B, s);
+    return launch_gn_res_bwd<14, 768>(p, B, s);
+  }
+  if (nl <= 1) return launch_gn_res_bwd<1, 1024>(p, B, s);
+  if (nl <= 2) return launch_gn_res_bwd<2, 1024>(p, B, s);
+  if (nl <= 3) return launch_gn_res_bwd<3, 1024>(p, B, s);
+  if (nl <= 4) return launch_gn_res_bwd<4, 1024>(p, B, s);
+  if (nl <= 6) return launch_gn_res_bwd<6, 1024>(p, B, s);
+  if (nl <= 8) return launch_gn_res_bwd<8, 1024>(p, B, s);
+  return launch_gn_res_bwd<11, 1024>(p, B, s);
+}
+
 }  // namespace
 
 extern "C" long da_norm_scratch_floats(int B, int HW, int C) {
@@ -790,6 +1239,16 @@ extern "C" int da_groupnorm_fwd(const void* X, long ldx, void* Y, long ldy, cons
                                 float eps, int silu, hipStream_t stream) {
   DA_CLEAR_ERR();
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 7) || (ldx & 7) || (ldy & 7)) return DA_ERR_SHAPE;
+  if (g_gn_resident) {
+    GnResParams r = {};
+    int nl = 0, threads = 0;
+    if (gn_res_plan(B, HW, C, G, ldx < ldy ? ldx : ldy, ldx > ldy ? ldx : ldy, false, r, nl, threads)) {
+      r.X = (const bf16*)X; r.ldx = ldx; r.OUT = (bf16*)Y; r.ldo = ldy; r.gamma = gamma; r.beta = beta;
+      r.mean_rstd = mean_rstd; r.HW = HW; r.C = C; r.G = G; r.cpg = C / G; r.silu = silu; r.eps = eps;
+      r.inv_n = 1.0f / ((float)(C / G) * (float)HW);
+      return dispatch_gn_res_fwd(nl, r, B, stream);
+    }
+  }
   ChanReduceParams p = {};
   p.X = (const bf16*)X; p.ldx = ldx; p.partial = scratch;
   p.HW = HW; p.C = C; p.G = G; p.cpg = C / G; p.nchunks = pick_chunks(B, HW);
@@ -814,6 +1273,27 @@ extern "C" int da_groupnorm_bwd(const void* X, long ldx, const void* dY, long ld
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7))
     return DA_ERR_SHAPE;
   if (Radd && (ldr & 7)) return DA_ERR_SHAPE;
+  if (g_gn_resident) {
+    GnResParams r = {};
+    int nl = 0, threads = 0;
+    long ldm = ldx < lddy ? ldx : lddy, ldM = ldx > lddy ? ldx : lddy;
+    if (lddx < ldm) ldm = lddx;
+    if (lddx > ldM) ldM = lddx;
+    if (Radd && ldr > ldM) ldM = ldr;
+    if (gn_res_plan(B, HW, C, G, ldm, ldM, true, r, nl, threads)) {
+      r.X = (const bf16*)X; r.ldx = ldx; r.DY = (const bf16*)dY; r.lddy = lddy; r.Radd = (const bf16*)Radd; r.ldr = ldr;
+      r.OUT = (bf16*)dX; r.ldo = lddx; r.gamma = gamma; r.beta = beta; r.mean_rstd = const_cast<float*>(mean_rstd);
+      r.partial = scratch; r.HW = HW; r.C = C; r.G = G; r.cpg = C / G; r.silu = silu;
+      r.inv_n = 1.0f / ((float)(C / G) * (float)HW);
+      int rc = dispatch_gn_res_bwd(nl, threads, r, B, stream);
+      if (rc) return rc;
+      // dbeta[c] (+)= sum_b s1, dgamma[c] (+)= sum_b s2: one partial row per image
+      hipLaunchKernelGGL(chan_sum_finalize_kernel, chan_sum_grid(B, C), dim3(CSF_CH * CSF_RL), 0, stream, scratch, B, C, dbeta,
+                         dgamma, g_grad_overwrite);
+      DA_CHECK_LAUNCH();
+      return DA_OK;
+    }
+  }
   ChanReduceParams p = {};
   p.X = (const bf16*)X; p.ldx = ldx; p.DY = (const bf16*)dY; p.lddy = lddy;
   p.mean_rstd = mean_rstd; p.gamma = gamma; p.beta = beta; p.partial = scratch;

@@ -71,6 +71,10 @@ int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* 
  *   "gemm_nt_persist_conv" 1 (default) 3x3 convolutions with more tiles than CUs also run as a resident tile walk (next tile's
  *                       descriptors + first K-step ahead of the epilogue; +0...1.4 %, bit-identical) | 0 one workgroup per tile
  *   "gemm_tn_variant"   0 auto | 1 the 128x128x32 wgrad kernel | 2 the 320x192x64 LDS-DMA wgrad kernel
+ *   "gn_resident"       n (default 192): da_groupnorm_fwd / _bwd run as ONE kernel that holds a workgroup's (image, whole groups)
+ *                       slab in registers - x (and dy) are read once - when the slab fits and the launch has >= n workgroups;
+ *                       0 never (always the reduce / finalize / apply passes), 1 whenever the slab fits
+ *   "gn_resident_form"  0 (default) auto | 1 16-wave backward forms only | 2 the 12-wave backward form above 8 vectors/thread
  *   "grad_overwrite"    0 (default) the gradient-producing entry points ADD to their outputs, as documented below | 1 they WRITE
  *                       them (da_gemm_tn_wgrad's dW and dbias, da_colsum_accum, da_image_colsum's db, dgamma / dbeta of
  *                       da_groupnorm_bwd / da_layernorm_bwd): set by the host around the first backward of an optimizer step,
@@ -119,11 +123,15 @@ long da_norm_scratch_floats(int B, int HW, int C);
 
 /* GroupNorm (+ optional fused SiLU) over [B][HW][C], G groups.  Replaces torch.nn.GroupNorm / Composer
  * LPGroupNorm (train.py:91-99) + F.silu in ResnetBlock2D / Transformer2DModel / conv_norm_out.
- * mean_rstd[B][G][2] is saved for backward; scale_shift[B][C][2] is scratch. */
+ * mean_rstd[B][G][2] is saved for backward; scale_shift[B][C][2] is scratch (untouched when the single-pass form runs).
+ * Single pass (see "gn_resident"): a 1024-thread workgroup owns HW pixels x CW channels (whole groups) of one image in
+ * registers, so the tensor crosses HBM once in and once out; otherwise statistics, finalize and apply are three launches. */
 int da_groupnorm_fwd(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta,
                      float* mean_rstd, float* scale_shift, float* scratch, int B, int HW, int C, int G, float eps,
                      int silu, da_stream_t stream);
-/* dX = GN(+SiLU) backward (+ Radd if non-null); dgamma/dbeta accumulated (+=); coef[B][G][2] scratch. */
+/* dX = GN(+SiLU) backward (+ Radd if non-null); dgamma/dbeta accumulated (+=); coef[B][G][2] scratch.  In the single-pass
+ * form x and dy stay in registers between the group sums and the dx sweep, and Radd is added to the bf16-rounded dX (as a
+ * separate add of two bf16 tensors would); the multi-pass form adds it in fp32 before rounding. */
 int da_groupnorm_bwd(const void* X, long ldx, const void* dY, long lddy, const void* Radd, long ldr, void* dX,
                      long lddx, const float* gamma, const float* beta, const float* mean_rstd, float* dgamma,
                      float* dbeta, float* coef, float* scratch, int B, int HW, int C, int G, int silu,

@@ -493,6 +493,70 @@ def test_groupnorm(ops, dev, B, HW, C, silu):
     check(db - 1, br.grad, tol=3e-3, what='gn dbeta')
 
 
+def _gn_run(ops, dev, B, HW, C, silu, use_radd, pad):
+    G = 32
+    xbuf = rnd(B * HW, C + pad, dev=dev, seed=1, scale=2.0).to(BF) + 0.5
+    x = xbuf[:, pad // 2:pad // 2 + C]
+    gamma = 1 + 0.1 * rnd(C, dev=dev, seed=2)
+    beta = 0.1 * rnd(C, dev=dev, seed=3)
+    y = torch.empty(B * HW, C, device=dev, dtype=BF)
+    mr = torch.empty(B * G * 2, device=dev); ss = torch.empty(B * C * 2, device=dev)
+    scratch = torch.empty(ops.norm_scratch_floats(B, HW, C), device=dev)
+    ops.groupnorm_fwd(x, y, gamma, beta, mr, ss, scratch, B, HW, C, G, 1e-5, silu)
+    dy = rnd(B * HW, C, dev=dev, seed=4).to(BF)
+    radd = rnd(B * HW, C, dev=dev, seed=5).to(BF) if use_radd else None
+    dx = torch.empty(B * HW, C, device=dev, dtype=BF)
+    dg = torch.ones(C, device=dev); db = torch.ones(C, device=dev)
+    coef = torch.empty(B * G * 2, device=dev)
+    ops.groupnorm_bwd(x, dy, radd, dx, gamma, beta, mr, dg, db, coef, scratch, B, HW, C, G, silu)
+    torch.cuda.synchronize()
+    return x, gamma, beta, y, mr.clone(), dy, radd, dx, dg, db
+
+
+@pytest.mark.parametrize('B,HW,C,silu,radd,pad', [
+    (8, 1024, 320, 1, 1, 0), (8, 1024, 320, 0, 0, 16), (3, 1024, 640, 1, 1, 0), (8, 1024, 960, 1, 0, 0),
+    (8, 256, 320, 1, 1, 0), (8, 256, 640, 1, 0, 64), (5, 256, 960, 0, 1, 0), (8, 256, 1280, 1, 1, 0), (8, 256, 1920, 1, 0, 0),
+    (8, 64, 640, 1, 1, 0), (8, 64, 1280, 0, 1, 0), (8, 64, 1920, 1, 1, 16), (8, 64, 2560, 1, 0, 0),
+    (8, 16, 1280, 1, 1, 0), (16, 16, 2560, 1, 1, 0), (2, 100, 320, 1, 1, 16), (2, 1024, 512, 1, 0, 0), (1, 4096, 256, 1, 1, 0)])
+def test_groupnorm_resident(ops, dev, B, HW, C, silu, radd, pad):
+    """The register-resident single-pass GroupNorm (forced: gn_resident=1) against torch fp32 and against the multi-pass
+    kernels on the same inputs, both thread forms of the backward; run to run bit-identical (fixed-order sums)."""
+    G = 32
+    try:
+        ops.set_option('gn_resident', 0)
+        base = _gn_run(ops, dev, B, HW, C, silu, radd, pad)
+        outs = []
+        for form in (0, 2, 0):
+            ops.set_option('gn_resident', 1)
+            ops.set_option('gn_resident_form', form)
+            outs.append(_gn_run(ops, dev, B, HW, C, silu, radd, pad))
+    finally:
+        ops.set_option('gn_resident', 192)
+        ops.set_option('gn_resident_form', 0)
+    x, gamma, beta = base[0], base[1], base[2]
+    xr = x.float().reshape(B, HW, C).permute(0, 2, 1).contiguous().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.group_norm(xr, G, gr, br, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    dy, ra = base[5], base[6]
+    ref.backward(dy.float().reshape(B, HW, C).permute(0, 2, 1))
+    dxr = xr.grad + (ra.float().reshape(B, HW, C).permute(0, 2, 1) if ra is not None else 0)
+    for r in outs:
+        _, _, _, y, mr, _, _, dx, dg, db = r
+        check(y.reshape(B, HW, C).permute(0, 2, 1), ref, what='resident gn fwd')
+        check(dx.reshape(B, HW, C).permute(0, 2, 1), dxr, what='resident gn dx')
+        check(dg - 1, gr.grad, tol=3e-3, what='resident gn dgamma')
+        check(db - 1, br.grad, tol=3e-3, what='resident gn dbeta')
+        # against the multi-pass kernels: same arithmetic up to summation order and the bf16 rounding before + Radd
+        assert (mr - base[4]).abs().max().item() <= 2e-5 * max(1.0, base[4].abs().max().item())
+        assert (y.float() - base[3].float()).abs().max().item() <= 4e-2
+        assert rel_l2(y.float(), base[3].float()) < 1e-3
+        assert rel_l2(dx.float(), base[7].float()) < 4e-3
+    for i in (3, 4, 7, 8, 9):   # same form twice: bit-identical
+        assert torch.equal(outs[0][i], outs[2][i])
+
+
 @pytest.mark.parametrize('M,C', [(300, 320), (77, 1280), (1000, 64), (64, 640)])
 def test_layernorm(ops, dev, M, C):
     x = (rnd(M, C, dev=dev, seed=1, scale=1.5) + 0.3).to(BF)

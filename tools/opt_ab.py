@@ -57,6 +57,37 @@ if 'geglu' in kinds:
             ma, mb = st.median(ts[va]), st.median(ts[vb])
             print(f'{name} M={M:6d} inner={inner:5d} K={K:5d} | {opt}={va}: {ma*1e3:7.1f} us {fl/ma/1e9:7.1f} TF/s | ={vb}: {mb*1e3:7.1f} us {fl/mb/1e9:7.1f} TF/s | x{ma/mb:.3f}', flush=True)
 
+if 'gn' in kinds:   # every GroupNorm shape of the U-Net at this batch: forward, backward (with and without the residual add)
+    G = 32
+    for (h, c) in ((32, 320), (32, 640), (32, 960), (16, 320), (16, 640), (16, 960), (16, 1280), (16, 1920), (8, 640), (8, 1280),
+                   (8, 1920), (8, 2560), (4, 1280), (4, 2560)):
+        HW = h * h
+        x = (torch.randn(B * HW, c, device=dev) * 2 + 0.5).to(BF); dy = torch.randn(B * HW, c, device=dev).to(BF)
+        ra = torch.randn(B * HW, c, device=dev).to(BF)
+        y = torch.empty_like(x); dx = torch.empty_like(x)
+        gam = 1 + 0.1 * torch.randn(c, device=dev); bet = 0.1 * torch.randn(c, device=dev)
+        mr = torch.empty(B * G * 2, device=dev); ss = torch.empty(B * c * 2, device=dev); coef = torch.empty(B * G * 2, device=dev)
+        dg = torch.zeros(c, device=dev); db = torch.zeros(c, device=dev)
+        scr = torch.empty(ops.norm_scratch_floats(B, HW, c), device=dev)
+        fns = (('fwd', lambda: ops.groupnorm_fwd(x, y, gam, bet, mr, ss, scr, B, HW, c, G, 1e-5, 1), 2, y),
+               ('bwd', lambda: ops.groupnorm_bwd(x, dy, None, dx, gam, bet, mr, dg, db, coef, scr, B, HW, c, G, 1), 3, dx),
+               ('bwd+r', lambda: ops.groupnorm_bwd(x, dy, ra, dx, gam, bet, mr, dg, db, coef, scr, B, HW, c, G, 1), 4, dx))
+        for name, fn, passes, out in fns:
+            ts, outs = {va: [], vb: []}, {}
+            for v in (va, vb):
+                ops.set_option(opt, v)
+                fn(); outs[v] = out.float().clone()
+            for rnd in range(5):
+                for v in (va, vb):
+                    ops.set_option(opt, v)
+                    fn(); ts[v].append(once(fn, 10))
+            ma, mb = statistics.median(ts[va]), statistics.median(ts[vb])
+            gb = passes * B * HW * c * 2 / 1e9
+            rel = ((outs[va] - outs[vb]).norm() / outs[va].norm()).item()
+            print(f'gn {name:5s} HW={HW:5d} C={c:5d} | {opt}={va}: {ma*1e3:7.1f} us {gb/ma:6.2f} TB/s | ={vb}: {mb*1e3:7.1f} us {gb/mb:6.2f} TB/s '
+                  f'(of {passes} passes) | x{ma/mb:.3f} rel-diff {rel:.1e}', flush=True)
+        del x, dy, ra, y, dx
+
 for h, cin, cout, k in shapes:
     M = B * h * h
     x = torch.randn(M, cin, device=dev).to(BF)
