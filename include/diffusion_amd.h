@@ -74,6 +74,7 @@ int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* 
  *   "gn_resident"       n (default 192): da_groupnorm_fwd / _bwd run as ONE kernel that holds a workgroup's (image, whole groups)
  *                       slab in registers - x (and dy) are read once - when the slab fits and the launch has >= n workgroups;
  *                       0 never (always the reduce / finalize / apply passes), 1 whenever the slab fits
+ *   "gn_resident_min_slab" bytes (default 65536) of one tensor per workgroup below which the multi-pass form runs
  *   "gn_resident_form"  0 (default) auto | 1 16-wave backward forms only | 2 the 12-wave backward form above 8 vectors/thread
  *   "grad_overwrite"    0 (default) the gradient-producing entry points ADD to their outputs, as documented below | 1 they WRITE
  *                       them (da_gemm_tn_wgrad's dW and dbias, da_colsum_accum, da_image_colsum's db, dgamma / dbeta of

@@ -39,6 +39,34 @@ def test_header_arity_matches_ctypes_signatures():
         assert n == len(_lib.SIGNATURES[name]), (name, n, len(_lib.SIGNATURES[name]))
 
 
+def test_set_option_keys_and_ranges(tmp_path):
+    """da_set_option is host-only state: every documented key is accepted, unknown keys and out-of-range values are rejected
+    (DA_ERR_SHAPE), and DA_SET_OPTIONS applies / rejects the same way at library load (checked in a child process)."""
+    import subprocess
+    import sys
+    from diffusion_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'diffusion_amd.h')).read()
+    doc = hdr[hdr.index('int da_set_option') - 6000:hdr.index('int da_set_option')]
+    keys = re.findall(r'^ \*   "([a-z0-9_]+)"', doc, flags=re.M)
+    assert {'gn_resident', 'gn_resident_form', 'reserve_cus', 'grad_overwrite', 'gemm_nt_persist_conv'} <= set(keys)
+    defaults = {'gn_resident': 192, 'gn_resident_min_slab': 65536, 'gemm_nt_persist': -1, 'gemm_nt_dispatch': 1, 'gemm_nt_korder': 1, 'gemm_nt_splitk': 1,
+                'gemm_nt_persist_conv': 1}
+    for k in keys:
+        assert lib.da_set_option(k.encode(), defaults.get(k, 0)) == 0, k
+    assert lib.da_set_option(b'no_such_option', 1) != 0
+    assert lib.da_set_option(b'reserve_cus', 129) != 0 and lib.da_set_option(b'reserve_cus', -1) != 0
+    assert lib.da_set_option(b'gn_resident', -1) != 0 and lib.da_set_option(b'gn_resident_form', 3) != 0
+    code = 'from diffusion_amd import _lib; _lib.load(); print("loaded")'
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ok = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(os.environ, DA_SET_OPTIONS='gn_resident=0,reserve_cus=8'),
+                        capture_output=True, text=True)
+    assert ok.returncode == 0 and 'loaded' in ok.stdout, ok.stderr
+    bad = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(os.environ, DA_SET_OPTIONS='gn_resident=0,bogus=1'),
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and 'DA_SET_OPTIONS' in bad.stderr
+
+
 def test_no_cpu_fallback():
     if torch.cuda.is_available():
         pytest.skip('GPU present')
