@@ -227,6 +227,11 @@ def main():
                 fl = sum(f for _, _, f in evs)
                 kern[k] = {'launches': len(evs), 'ms': round(ms, 2), 'avg_us': round(1000 * ms / len(evs), 2),
                            'tflops': round(fl / ms / 1e9, 1) if ms > 0 else None}
+            if 'attn_bwd' in kern and kern['attn_bwd']['tflops']:
+                # counted as 2 x forward (four N x N x 64 products), consistent with SURVEY 8(d)'s train = 3 x fwd; the
+                # FlashAttention convention counts the recomputed S as well (five products, 2.5 x forward)
+                kern['attn_bwd']['flops_convention'] = '8*B*H*Nq*Nk*64 (2 x forward)'
+                kern['attn_bwd']['tflops_5_products'] = round(kern['attn_bwd']['tflops'] * 1.25, 1)
             dom = max((k for k in kern if k.startswith('gemm_nt')), key=lambda k: kern[k]['ms'])
             gk = kern[dom]
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'profiled_steps': PROFILE_STEPS, 'achieved': gk['tflops'],

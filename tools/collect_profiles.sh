@@ -6,7 +6,7 @@
 #   gpurun_out/final/stats/                    rocprofv3 --kernel-trace --stats of the default bench command
 #   gpurun_out/final/pmc_fetch/, pmc_write/    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes
 #   gpurun_out/final/bench_mb16.json           the reference YAML's device_train_microbatch_size: 16 (SD-2-base-256.yaml:87)
-#   gpurun_out/final/bench_cfg3.json           BASELINE cfg 3: online VAE + text encode, batch 64
+#   gpurun_out/final/bench_cfg3.json           BASELINE cfg 3: online VAE + text encode, batch 64 (and _b256: batch 256 = 2048 / 8 GPUs)
 #   gpurun_out/final/bench_768v.json           BASELINE cfg 5: SD-2.1-768-v, latents 4x96x96, batch 16
 # Copy the summaries into profiles/ afterwards (tools/pmc_hbm_summary.py gpurun_out/final profiles/${ROUND}_pmc_hbm_traffic.json).
 set -o pipefail
@@ -24,6 +24,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o
 echo "pmc done"
 python3 $R/bench.py --microbatch 16 --no-cpu-baseline --no-kernel-timing --no-secondary --steps 3 --warmup 1 > $O/bench_mb16.json 2> $O/bench_mb16.err || exit 1
 python3 $R/bench.py --full-pipeline --batch 64 --microbatch 64 --no-cpu-baseline --no-kernel-timing --no-secondary --steps 5 --warmup 2 > $O/bench_cfg3.json 2> $O/bench_cfg3.err || exit 1
+python3 $R/bench.py --full-pipeline --batch 256 --microbatch 256 --no-cpu-baseline --no-kernel-timing --no-secondary --steps 3 --warmup 1 > $O/bench_cfg3_b256.json 2> $O/bench_cfg3_b256.err || exit 1
 python3 $R/bench.py --latent 96 --no-cpu-baseline --no-kernel-timing --no-secondary --steps 5 --warmup 2 > $O/bench_768v.json 2> $O/bench_768v.err || exit 1
 echo "extras done"
 ls -R $O | head -40
