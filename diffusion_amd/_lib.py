@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdiffusion_amd.so')
+# DA_LIB_ALT=<file name>: another build of the library next to the shipped one (whole-program A/B of compile-time variants)
+LIB_PATH = os.path.join(_HERE, os.environ.get('DA_LIB_ALT') or 'libdiffusion_amd.so')
 
 _vp, _l, _i, _f, _fp, _ll = C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_void_p, C.c_void_p
 

@@ -185,12 +185,13 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   const int nblk = p.tiles_m * p.tiles_n;
   int split, tn, m0, n0;  // the tile the DMA descriptors below belong to (wave-uniform)
   auto locate = [&](int vb) {
-    split = PERSIST ? (int)fdiv((unsigned)vb, p.div_nblk) : vb / nblk;  // splits of a tile are nblk workgroups apart
+    // (FastDiv only in the persistent convolution form: in the persistent linear form it costs 7 spills - measured -6...-16 %)
+    split = (PERSIST && !EARLY) ? (int)fdiv((unsigned)vb, p.div_nblk) : vb / nblk;  // splits of a tile are nblk workgroups apart
     int bid = vb - split * nblk;
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tm = PERSIST ? (int)fdiv((unsigned)bid, p.div_tn) : bid / p.tiles_n;
+    const int tm = (PERSIST && !EARLY) ? (int)fdiv((unsigned)bid, p.div_tn) : bid / p.tiles_n;
     tn = bid - tm * p.tiles_n;
     m0 = tm * V2_BM;
     n0 = tn * BN;
@@ -706,7 +707,7 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
           }
         }
         if (p.rowbias) {
-          const int b = PERSIST ? (int)fdiv((unsigned)m, p.div_hw) : m / HWo;
+          const int b = (PERSIST && !EARLY) ? (int)fdiv((unsigned)m, p.div_hw) : m / HWo;
           const bf16x8 rbv = ld8(p.rowbias + (long)b * p.ldrb + n);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bf2f(rbv[e]);

@@ -67,6 +67,35 @@ def test_set_option_keys_and_ranges(tmp_path):
     assert bad.returncode != 0 and 'DA_SET_OPTIONS' in bad.stderr
 
 
+def test_kernel_spill_budget():
+    """The build leaves each object's register report (csrc/<file>.ru.txt, -Rpass-analysis=kernel-resource-usage).  No kernel of
+    the library may spill except the four recorded ones (2 VGPRs each, outside their inner loops): a template edit that pushed
+    the persistent linear form of gemm_nt2 from 0 to 7 spills cost 6-16 % on its shapes and no numerical test noticed."""
+    import glob
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'diffusion_amd', 'csrc')
+    reports = sorted(glob.glob(os.path.join(csrc, '*.ru.txt')))
+    if len(reports) < 7:
+        import subprocess
+        subprocess.run(['make', '-C', csrc, '-B', '-j4'], check=True, capture_output=True)
+        reports = sorted(glob.glob(os.path.join(csrc, '*.ru.txt')))
+    assert len(reports) >= 7
+    allowed = {   # mangled-name fragment -> spilled VGPRs allowed
+        'gemm_nt2_kernelILi4ELi5ELi4ELi4ELi64ELb0ELi0ELb0ELi16ELb1E': 2,     # persistent 3x3 convolution form
+        'gemm_nt2_kernelILi4ELi5ELi4ELi4ELi64ELb0ELi2ELb1ELi16ELb1E': 2,     # fused GEGLU backward
+        'gn_res_bwd_kernelILi11ELb1ELi1024E': 2, 'gn_res_bwd_kernelILi11ELb0ELi1024E': 2}
+    seen = 0
+    for f in reports:
+        txt = open(f).read()
+        names = re.findall(r'Function Name: (\S+)', txt)
+        spills = [int(x) for x in re.findall(r'VGPRs Spill: (\d+)', txt)]
+        assert len(names) == len(spills) and names, f
+        for n, sp in zip(names, spills):
+            seen += 1
+            budget = max([v for k, v in allowed.items() if k in n] or [0])
+            assert sp <= budget, f'{n}: {sp} spilled VGPRs (budget {budget}) in {os.path.basename(f)}'
+    assert seen > 100
+
+
 def test_no_cpu_fallback():
     if torch.cuda.is_available():
         pytest.skip('GPU present')
