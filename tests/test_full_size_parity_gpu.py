@@ -155,6 +155,31 @@ def test_full_width_train_step_vs_oracle_fixture(full, dev, case):
     _check_step(O, sd, model, dev, cfg_name, latents, ctx, noise, t, fx, G.SLICES, case)
 
 
+@pytest.mark.parametrize('case', ['s32', 's64'])
+def test_full_width_train_step_single_pass_groupnorm(full, dev, case):
+    """The same oracle-checked steps with the register-resident GroupNorm kernels forced (gn_resident=1, no slab floor): at
+    the fixtures' batch of 1-2 the default dispatch (>= 192 workgroups) keeps the multi-pass kernels, at the bench batch of
+    256 it takes the single-pass ones - which must meet the same bounds.  (At S=64 the level-0 slabs do not fit: mixed.)"""
+    import make_golden_full as G
+    from diffusion_amd import ops
+    O, sd, model = full
+    fname, cfg_name, B, S, wseed, iseed = G.CASES[case]
+    cfg = getattr(O.UNetConfig, cfg_name)()
+    latents, ctx, noise, t = G.inputs(B, S, cfg.cross_attention_dim, iseed)
+    fx = dict(np.load(os.path.join(GOLD, fname)))
+    same_streams = np.allclose(G.checksum(sd, latents, ctx, noise), fx['checksum'], rtol=0, atol=1e-6) and \
+        np.array_equal(fx['t'], t.numpy())
+    if not same_streams:
+        fx = _oracle_live(O, sd, cfg_name, latents, t, ctx, noise, G.SLICES)
+    try:
+        ops.set_option('gn_resident', 1)
+        ops.set_option('gn_resident_min_slab', 0)
+        _check_step(O, sd, model, dev, cfg_name, latents, ctx, noise, t, fx, G.SLICES, case + '_single_pass_groupnorm')
+    finally:
+        ops.set_option('gn_resident', 192)
+        ops.set_option('gn_resident_min_slab', 65536)
+
+
 def test_full_pipeline_256px_unet_half_vs_oracle(full, dev):
     """BASELINE cfg 3: precomputed_latents=False.  The frozen VAE / text encoder (random-init PyTorch-ROCm modules) encode
     one 256x256 image + token ids; the HIP U-Net step on those latents is compared with the oracle fed the same
