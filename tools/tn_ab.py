@@ -12,7 +12,8 @@ VA, VB = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1, 2)
 ops.SPLITK_WS = torch.empty(32 * 1024 * 1024, device=dev, dtype=torch.float32)
 shapes = [(32, 320, 320, 3), (16, 640, 640, 3), (8, 1280, 1280, 3), (4, 1280, 1280, 3), (8, 2560, 1280, 3),
           (32, 320, 320, 1), (16, 640, 640, 1), (8, 1280, 1280, 1), (4, 1280, 1280, 1), (8, 1280, 10240, 1), (8, 5120, 1280, 1),
-          (4, 1280, 10240, 1), (4, 5120, 1280, 1)]
+          (4, 1280, 10240, 1), (4, 5120, 1280, 1), (32, 320, 960, 1), (32, 320, 2560, 1), (32, 1280, 320, 1), (16, 640, 1920, 1),
+          (16, 640, 5120, 1), (16, 2560, 640, 1)]
 
 
 def once(fn, iters):
