@@ -1161,13 +1161,8 @@ template <int NL, bool SILU>
 int launch_gn_res_fwd2(const GnResParams& p, int B, hipStream_t stream) {
   const size_t smem = gn_res_lds_floats(p.P, p.CW, p.nseg, p.cpg) * sizeof(float);
   if (smem > 160 * 1024) return DA_ERR_SHAPE;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)gn_res_fwd_kernel<NL, SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-        hipSuccess)
-      return DA_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (da_ensure_dyn_smem((const void*)gn_res_fwd_kernel<NL, SILU>, 160 * 1024, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
   hipLaunchKernelGGL((gn_res_fwd_kernel<NL, SILU>), dim3(B * p.parts), dim3(1024), smem, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
@@ -1182,13 +1177,8 @@ template <int NL, bool SILU, int T>
 int launch_gn_res_bwd2(const GnResParams& p, int B, hipStream_t stream) {
   const size_t smem = gn_res_lds_floats(p.P, p.CW, p.nseg, p.cpg) * sizeof(float);
   if (smem > 160 * 1024) return DA_ERR_SHAPE;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)gn_res_bwd_kernel<NL, SILU, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return DA_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (da_ensure_dyn_smem((const void*)gn_res_bwd_kernel<NL, SILU, T>, 160 * 1024, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
   hipLaunchKernelGGL((gn_res_bwd_kernel<NL, SILU, T>), dim3(B * p.parts), dim3(T), smem, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
