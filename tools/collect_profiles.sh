@@ -1,5 +1,6 @@
 #!/bin/bash
 # Collect the judged measurement artifacts on the GPU box (run through gpurun from the repo root; ROUND=r03 names them):
+#   gpurun_out/final/box_probe.txt             tools/box_probe.py: this box's streaming bandwidth and long-K conv rate
 #   gpurun_out/final/bench_256.json            the bench.py line (with the 512-px secondary block and cpu_baseline)
 #   gpurun_out/final/per_shape_in_situ.txt     BENCH_SHAPES=1: time / TFLOP/s per GEMM / attention shape inside the step,
 #                                              DEFAULT options, the shipped library
@@ -15,6 +16,9 @@ O=$R/gpurun_out/final
 ROUND=${ROUND:-r03}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+# which kind of box is this?  (the pool's MI355X differ by several per cent; PROBE_STRICT=1 stops on a slow one)
+PROBE_MIN_TFS=${PROBE_MIN_TFS:-1300} python3 $R/tools/box_probe.py > $O/box_probe.txt 2>&1 || { cat $O/box_probe.txt; [ -z "$PROBE_STRICT" ] || exit 3; }
+cat $O/box_probe.txt
 BENCH_SHAPES=1 python3 $R/bench.py > $O/bench_256.json 2> $O/per_shape_in_situ.txt || exit 1
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $ROUND -- python3 $R/bench.py --no-cpu-baseline --no-secondary > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
