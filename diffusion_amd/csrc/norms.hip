@@ -1140,7 +1140,9 @@ bool gn_res_plan(int B, int HW, int C, int G, long ld_min, long ld_max, bool bwd
       // multi-pass kernels, 160-KB ones 1.2-1.7x), the 16-wave form
       if ((long)HW * cw * 2 < g_gn_resident_min_slab) continue;
       if (gn_res_lds_floats(P, cw, T / cw < 1 ? 1 : T / cw, cpg) * sizeof(float) > 160 * 1024) continue;
-      cost += 0.01 * ti - 0.002 * n;
+      // ... then the form whose last sweep is fuller: HW / (P * n) of the loads carry data (1,024 px x 10 chunks: 0.91 with
+      // 1,024 threads x 11 vectors, 0.96 with 768 x 14 - measured +2...5 % for the latter, -18 % where it forces a narrower slab)
+      cost += 0.8 * (1.0 - (double)HW / ((double)P * n)) + 0.01 * ti - 0.002 * n * T / 1024.0;
       if (wgs < 256) cost += 0.05;
       if (cost < best) { best = cost; best_cw = cw; best_t = T; }
     }
