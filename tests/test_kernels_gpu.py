@@ -517,7 +517,8 @@ def _gn_run(ops, dev, B, HW, C, silu, use_radd, pad):
     (8, 1024, 320, 1, 1, 0), (8, 1024, 320, 0, 0, 16), (3, 1024, 640, 1, 1, 0), (8, 1024, 960, 1, 0, 0),
     (8, 256, 320, 1, 1, 0), (8, 256, 640, 1, 0, 64), (5, 256, 960, 0, 1, 0), (8, 256, 1280, 1, 1, 0), (8, 256, 1920, 1, 0, 0),
     (8, 64, 640, 1, 1, 0), (8, 64, 1280, 0, 1, 0), (8, 64, 1920, 1, 1, 16), (8, 64, 2560, 1, 0, 0),
-    (8, 16, 1280, 1, 1, 0), (16, 16, 2560, 1, 1, 0), (2, 100, 320, 1, 1, 16), (2, 1024, 512, 1, 0, 0), (1, 4096, 256, 1, 1, 0)])
+    (8, 16, 1280, 1, 1, 0), (16, 16, 2560, 1, 1, 0), (2, 100, 320, 1, 1, 16), (2, 1024, 512, 1, 0, 0), (1, 4096, 256, 1, 1, 0),
+    (8, 256, 96, 1, 1, 0), (4, 49, 64, 0, 1, 16), (3, 1, 320, 1, 0, 0), (2, 2304, 640, 1, 1, 0)])
 def test_groupnorm_resident(ops, dev, B, HW, C, silu, radd, pad):
     """The register-resident single-pass GroupNorm (forced: gn_resident=1) against torch fp32 and against the multi-pass
     kernels on the same inputs, both thread forms of the backward; run to run bit-identical (fixed-order sums)."""
