@@ -785,9 +785,10 @@ __global__ __launch_bounds__(256) void ln_bwd5_kernel(const bf16* X, long ldx, c
 // ---- GroupNorm with the slab resident in registers ("single pass"): a 1024-thread workgroup owns HW pixels x CW channels
 // of ONE image (CW = whole groups, a multiple of 8), loads that slab with every 16-B load in flight at once, reduces it,
 // and rewrites it from registers - x (and dy) cross the fabric once instead of twice.  Thread t keeps chunk j = t % chunks
-// (8 channels) of pixels t / chunks + k*P, k < NL.  The arithmetic runs channel-outer / pixel-inner so that only one
-// channel's coefficients and accumulators are live beside the NL (forward) or 2*NL (backward) data vectors: the backward
-// form must fit 2 x 11 vectors + everything else in the 128 VGPRs a 16-wave workgroup gets.
+// (8 channels) of pixels t / chunks + k*P, k < NL.  The arithmetic runs channel-pair-outer / pixel-inner so that only one
+// pair's coefficients and accumulators are live beside the NL (forward) or 2*NL (backward) data vectors: the backward
+// form must fit 2 x 11 vectors + everything else in the 128 VGPRs a 16-wave workgroup gets (or 2 x 14 in the 168 of the
+// 12-wave form, which gn_res_plan takes when its last sweep is fuller).
 // The parts of one image sit 8 workgroup ids apart (same XCD): when CW*2 bytes is not a multiple of the 128-B line
 // (320 channels = 32 groups of 10) neighbouring parts share lines, and the shared lines are then served by one L2.
 // Measured (tools/slab_pass.hip, 256 x 1024 px x 320 ch): forward 2 x 160 channels 5.6 TB/s of useful bytes, backward
