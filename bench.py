@@ -22,15 +22,14 @@ import os
 import sys
 import time
 
-# multi-process GPU work on this pool needs dmabuf IPC (RCCL / cross-process tensor sharing fail with the legacy mode);
-# must be in the environment before the HIP runtime starts
-os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# importing the package puts HSA_ENABLE_IPC_MODE_LEGACY=0 into the environment (diffusion_amd/__init__.py: the one place
+# run.py, bench.py and the tests share) before torch can start the HIP runtime
+import diffusion_amd  # noqa: E402,F401
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 TRAIN_GFLOP_PER_IMG = {32: 543.27, 64: 2412.77, 96: 6447.32}  # fwd+dgrad+wgrad, 2*MAC
 PROFILE_STEPS = 2      # instrumented steps behind `roofline` / `kernels` (outside the timed region)
@@ -105,6 +104,25 @@ def cpu_baseline(seconds_budget=30.0):
                                                 'cost is batch-independent on this path'))}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves, the way the reference's
+    `composer run.py` spawns its own (README.md:86-93, sensecore/run_cmd.sh:23-33).  The parent makes NO GPU call (it
+    never touches torch.cuda), relays the children's output - rank 0 prints the one JSON line - and returns their status."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, _usable_cores() // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -121,6 +139,8 @@ def main():
                          '(random-init fp16 encoders, synthetic images / token ids) inside the timed step')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(a.gpus))
     from diffusion_amd.parallel import init_distributed_from_env
     rank, local, world = init_distributed_from_env()
     if world != a.gpus:
@@ -211,7 +231,9 @@ def main():
             'ms_per_step': round(1000 * dt / a.steps, 2), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': (round(ips / README_8xA100[S], 3) if (world == 8 and S in README_8xA100) else None),
             'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'SD-2-base U-Net train step, latents 4x{S}x{S}, text 77x1024, batch {B}/GPU '
+            'config': {'workload': f'{"SD-2.1-768-v (v-prediction)" if S == 96 else "SD-2-base"} U-Net train step, '
+                                   + ('online VAE + CLIP text encode, ' if a.full_pipeline else '') +
+                                   f'latents 4x{S}x{S}, text 77x1024, batch {B}/GPU '
                                    f'(global {B * world}), microbatch {mb}, AdamW, dp{world}',
                        'global_batch': B * world, 'microbatch': mb, 'parallelism': f'dp{world}',
                        'params': model.unet.num_params},
@@ -241,7 +263,7 @@ def main():
             # process); the committed summary of those passes over this same command is reported with its provenance
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))
-            if S == 32 and cands:
+            if S == 32 and B == 256 and mb == 256 and not a.full_pipeline and cands:
                 tp = cands[-1]
                 with open(tp) as f:
                     pm = json.load(f)

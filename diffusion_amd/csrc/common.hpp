@@ -127,7 +127,9 @@ DEVINL float dgelu_f(float x) {
   return fmaf(x * 0.39894228040143268f, e, cdf);
 }
 
-// exact n / d for n < 2^24, d >= 1:  q = (n * magic) >> 40, magic = floor(2^40/d)+1  (host computes magic)
+// q = (n * magic) >> 40, magic = floor(2^40/d)+1 (host computes magic).  With e = magic*d - 2^40 in (0, d] the quotient is
+// exact while n * e < 2^40, i.e. for every n with n * d < 2^40 (and n < 2^24 so that n * magic fits 64 bits at d = 1):
+// the launchers check both (tests/test_abi_and_host.py::test_fastdiv_exact_at_the_admitted_bounds mirrors the arithmetic)
 struct FastDiv {
   unsigned long long magic;
   unsigned int d;

@@ -855,7 +855,7 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
   p.total_blocks = p.tiles_m * p.tiles_n * p.splits;
   p.div_nblk = make_fastdiv((unsigned)(p.tiles_m * p.tiles_n));
   p.div_tn = make_fastdiv((unsigned)p.tiles_n);
-  if (PERSIST && (p.total_blocks >= (1 << 24) || p.M >= (1 << 24))) return DA_ERR_SHAPE;  // FastDiv range
+  if (PERSIST && (p.total_blocks >= (1 << 20) || p.M >= (1 << 24))) return DA_ERR_SHAPE;  // FastDiv range: n * d < 2^40
   const int grid = PERSIST ? persistent_grid(p.total_blocks) : p.total_blocks;
   if (p.splits > 1) {
     GemmNT2Params pk = p;
@@ -889,7 +889,7 @@ int launch_v2_geglu(GemmNT2Params p, hipStream_t stream) {
   p.total_blocks = p.tiles_m * p.tiles_n;
   p.div_nblk = make_fastdiv((unsigned)p.total_blocks);
   p.div_tn = make_fastdiv((unsigned)p.tiles_n);
-  if (p.total_blocks >= (1 << 24) || p.M >= (1 << 24)) return DA_ERR_SHAPE;  // FastDiv range
+  if (p.total_blocks >= (1 << 20) || p.M >= (1 << 24)) return DA_ERR_SHAPE;  // FastDiv range: n * d < 2^40
   hipLaunchKernelGGL((gemm_nt2_kernel<4, 5, 4, 4, 64, false, GM, true>), dim3(persistent_grid(p.total_blocks)), dim3(1024), SMEM, stream, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
@@ -909,7 +909,7 @@ int launch_v2(const GemmNT2Params& p, int splits, float* ws, hipStream_t stream)
     // (da_set_option("gemm_nt_persist_conv", 0) = one tile per workgroup, as before round 3)
     const long tiles = (long)((p.M + 255) / 256) * ((p.N + 319) / 320) * (splits > 1 ? splits : 1);
     if (g_nt_persist_conv && g_nt_persist != 0 && p.ksize == 3 && p.mode == 0 && tiles > da_usable_cus(256) && p.N % 320 == 0 &&
-        p.M < (1 << 24) &&
+        p.M < (1 << 24) && (long)p.M * p.Hout * p.Wout < (1L << 40) &&   // FastDiv (common.hpp) exact while n * d < 2^40
         (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.lda * 2 < (1L << 32))
       return launch_v2_mode<MT, NT, WM, WN, BK, false, false, MF, true>(p, splits, ws, stream);
   }

@@ -236,6 +236,8 @@ extern "C" int da_gemm_tn_wgrad(const void* dY, long lddy, const void* X, long l
   if (mode != 0 && mode != 1 && mode != 3) return DA_ERR_SHAPE;
   if (M >= (1 << 24)) return DA_ERR_SHAPE;
   if (Hout <= 0 || Wout <= 0 || (M % (Hout * Wout))) return DA_ERR_SHAPE;
+  // FastDiv (common.hpp) is exact while n * d < 2^40: pixel index / (Hout*Wout), k' index / Cin
+  if (ksize == 3 && ((long)M * Hout * Wout >= (1L << 40) || 9L * Cin * Cin >= (1L << 40))) return DA_ERR_SHAPE;
   {
     const int Kt = ksize * ksize * Cin;
     if (tn_takes_v2(M, N, Kt))

@@ -148,6 +148,13 @@ class BucketedAllReducer:
             self._launch(lo, self.hi)
             self.hi = lo
 
+    def abort(self):
+        """Leave a step that raised: give the reserved CUs back and forget the unlaunched range."""
+        self.on_bucket = None
+        self.hi = 0
+        if self._reserved:
+            self._set_reserve(0)
+
     def flush(self):
         """Launch what is left ([0, hi)) and make the current stream wait for every bucket."""
         if not self.overlap:      # same bucket boundaries as the overlapped schedule would have produced
@@ -155,10 +162,12 @@ class BucketedAllReducer:
                 lo = ((self.hi - self.bucket) // self.align) * self.align
                 self._launch(lo, self.hi)
                 self.hi = lo
-        self._launch(0, self.hi)
-        self.hi = 0
-        if self._reserved:
-            self._set_reserve(0)
+        try:
+            self._launch(0, self.hi)
+        finally:
+            self.hi = 0
+            if self._reserved:
+                self._set_reserve(0)
         for h in self.handles:
             h.wait()
         if self.stream is not None and (self.enabled or self.on_bucket is not None):

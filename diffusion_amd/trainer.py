@@ -220,35 +220,41 @@ class Trainer:
         # AdamW slices behind each gradient bucket on the side stream: measured 196.4 vs 196.6 ms/step at N=1 (and 202 ms
         # with per-kernel events) - the slices only take CUs from the backward GEMMs - so it is opt-in
         sliced = self.sliced_optimizer and hasattr(opt, 'step_range')
-        for i, s in enumerate(starts):
-            sub = {k: (v[s:s + mb] if torch.is_tensor(v) else v) for k, v in batch.items()}
-            w = min(mb, n - s) / n
-            last = i == len(starts) - 1
-            graphed = self._graph_this(sub, len(starts), last)
-            if not graphed:
-                outputs = model(sub)
-                loss = model.loss(outputs, sub, weight=w)
-            if last:
-                # everything the optimizer step needs is known before the last backward: each gradient bucket is
-                # all-reduced and its AdamW slice issued on the side stream as soon as backward has finished it
-                if self.scheduler is not None:
-                    bpe = len(self.dataloader) if hasattr(self.dataloader, '__len__') else None
-                    opt.param_groups[0]['lr'] = self.base_lr * self.scheduler(self.batch_idx, bpe)
-                opt.grad_scale = 1.0 / self.world
-                for a in self.algorithms:
-                    a.before_optimizer_step(self)
-                if sliced and not graphed:
-                    opt.begin_step()
-                    self.reducer.on_bucket = opt.step_range
-            if graphed:
-                unet._grad_ready_cb = None
-                outputs, loss = self._graph_cache.step(sub, w)
-            else:
-                unet._grad_ready_cb = self.reducer.ready if last else None
-                model.backward_from_loss()
-            for m in model.get_metrics(is_train=True).values():
-                model.update_metric(sub, outputs, m)
-            total = total + loss.detach() * w
+        try:
+            for i, s in enumerate(starts):
+                sub = {k: (v[s:s + mb] if torch.is_tensor(v) else v) for k, v in batch.items()}
+                w = min(mb, n - s) / n
+                last = i == len(starts) - 1
+                graphed = self._graph_this(sub, len(starts), last)
+                if not graphed:
+                    outputs = model(sub)
+                    loss = model.loss(outputs, sub, weight=w)
+                if last:
+                    # everything the optimizer step needs is known before the last backward: each gradient bucket is
+                    # all-reduced and its AdamW slice issued on the side stream as soon as backward has finished it
+                    if self.scheduler is not None:
+                        bpe = len(self.dataloader) if hasattr(self.dataloader, '__len__') else None
+                        opt.param_groups[0]['lr'] = self.base_lr * self.scheduler(self.batch_idx, bpe)
+                    opt.grad_scale = 1.0 / self.world
+                    for a in self.algorithms:
+                        a.before_optimizer_step(self)
+                    if sliced and not graphed:
+                        opt.begin_step()
+                        self.reducer.on_bucket = opt.step_range
+                if graphed:
+                    unet._grad_ready_cb = None
+                    outputs, loss = self._graph_cache.step(sub, w)
+                else:
+                    unet._grad_ready_cb = self.reducer.ready if last else None
+                    model.backward_from_loss()
+                for m in model.get_metrics(is_train=True).values():
+                    model.update_metric(sub, outputs, m)
+                total = total + loss.detach() * w
+        except BaseException:
+            # an exception inside backward must not leave CUs reserved process-wide (da_set_option is global state)
+            unet._grad_ready_cb = None
+            self.reducer.abort()
+            raise
         unet._grad_ready_cb = None
         self.reducer.flush()
         self.reducer.on_bucket = None

@@ -8,11 +8,10 @@ Rank 0 writes {'grad': reduced flat gradient, 'before': master weights before th
 import os
 import sys
 
-os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import diffusion_amd  # noqa: E402,F401  (sets HSA_ENABLE_IPC_MODE_LEGACY=0 before the HIP runtime starts)
 import torch  # noqa: E402
 import torch.distributed  # noqa: E402
-
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 GLOBAL_BATCH, S, CTX = 8, 16, 128
 

@@ -74,10 +74,13 @@ def test_kernel_spill_budget():
     import glob
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'diffusion_amd', 'csrc')
     reports = sorted(glob.glob(os.path.join(csrc, '*.ru.txt')))
-    if len(reports) < 7:
+    if len(reports) < 7:   # fresh checkout (the reports are git-ignored): compile them into a scratch directory, link nothing
         import subprocess
-        subprocess.run(['make', '-C', csrc, '-B', '-j4'], check=True, capture_output=True)
-        reports = sorted(glob.glob(os.path.join(csrc, '*.ru.txt')))
+        import tempfile
+        tmp = tempfile.mkdtemp(prefix='da_ru_')
+        r = subprocess.run(['make', '-C', csrc, 'ru', f'RU_DIR={tmp}', '-j4'], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        reports = sorted(glob.glob(os.path.join(tmp, '*.ru.txt')))
     assert len(reports) >= 7
     allowed = {   # mangled-name fragment -> spilled VGPRs allowed
         'gemm_nt2_kernelILi4ELi5ELi4ELi4ELi64ELb0ELi0ELb0ELi16ELb1E': 2,     # persistent 3x3 convolution form
@@ -94,6 +97,30 @@ def test_kernel_spill_budget():
             budget = max([v for k, v in allowed.items() if k in n] or [0])
             assert sp <= budget, f'{n}: {sp} spilled VGPRs (budget {budget}) in {os.path.basename(f)}'
     assert seen > 100
+
+
+def test_fastdiv_exact_at_the_admitted_bounds():
+    """csrc/common.hpp FastDiv: q = (n * (2^40 // d + 1)) >> 40.  The launchers admit n < 2^24 with n * d < 2^40
+    (gemm_nt_v2.hip persistent forms, gemm_tn.hip); inside that range the quotient must be exact, and just outside
+    it must be able to fail - otherwise the guard is not the binding one."""
+    import random
+
+    def fdiv(n, d):
+        return ((n * ((1 << 40) // d + 1)) & ((1 << 64) - 1)) >> 40
+
+    rnd = random.Random(5)
+    ds = [1, 2, 3, 7, 32 * 32, 64 * 64, 96 * 96, 65535, 65536, 65537, 99991, 512 * 512, (1 << 20) - 1, 1 << 20]
+    ds += [rnd.randrange(1, 1 << 22) for _ in range(200)]
+    for d in ds:
+        nmax = min((1 << 24) - 1, ((1 << 40) - 1) // d)
+        cand = {0, 1, d - 1, d, d + 1, nmax, nmax - 1} | {k * d - 1 for k in range(1, 50)} | {k * d for k in range(1, 50)}
+        cand |= {nmax - (nmax % d) - 1, nmax - (nmax % d)} | {rnd.randrange(0, nmax + 1) for _ in range(300)}
+        for n in cand:
+            if 0 <= n <= nmax:
+                assert fdiv(n, d) == n // d, (n, d)
+    # beyond n * d < 2^40 the formula does go wrong (d = 512*512 output pixels, n just under 2^24)
+    d = 512 * 512
+    assert any(fdiv(k * d - 1, d) != (k * d - 1) // d for k in range(1, 64))
 
 
 def test_no_cpu_fallback():

@@ -14,8 +14,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return str(sk.getsockname()[1])
+
+
 def _run(out, nproc, extra_env=None):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=ROOT)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop('HSA_ENABLE_IPC_MODE_LEGACY', None)   # the package itself must set it (diffusion_amd/__init__.py)
     env.update(extra_env or {})
     worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
     if nproc == 1:
@@ -23,7 +31,7 @@ def _run(out, nproc, extra_env=None):
     else:
         env['DA_DIST_BACKEND'] = 'gloo'
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
-               '--master-addr', '127.0.0.1', '--master-port', '29617', worker, out]
+               '--master-addr', '127.0.0.1', '--master-port', _free_port(), worker, out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return torch.load(out)
@@ -59,7 +67,7 @@ def test_rccl_calls_execute_in_a_one_rank_group(single, tmp_path, collective, pa
     # DA_DP_RESERVE_CUS=0: with CUs reserved for the collective the weight-gradient pixel splits (and so the order of their
     # fixed-order sums) differ from the whole-chip run - covered by test_reserved_cus_and_sliced_adamw_... below
     env = {'DA_DP_FORCE': '1', 'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1',
-           'MASTER_PORT': '29618', 'DA_DP_COLLECTIVE': collective, 'DA_DP_PAYLOAD': payload, 'DA_DP_RESERVE_CUS': '0',
+           'MASTER_PORT': _free_port(), 'DA_DP_COLLECTIVE': collective, 'DA_DP_PAYLOAD': payload, 'DA_DP_RESERVE_CUS': '0',
            'DA_SLICED_ADAMW': '0'}
     one = _run(str(tmp_path / 'one.pt'), 1, env)
     assert one['backend'] == 'nccl' and one['reducer_enabled'] and one['buckets'] >= 3
@@ -79,10 +87,43 @@ def test_reserved_cus_and_sliced_adamw_in_a_one_rank_rccl_group(single, tmp_path
     (default when an exchange runs).  Same step as the plain run up to the summation order of the re-split weight-gradient
     grids; the sliced optimizer step lands on the same weights."""
     env = {'DA_DP_FORCE': '1', 'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1',
-           'MASTER_PORT': '29619', 'DA_DP_RESERVE_CUS': '16', 'DA_SLICED_ADAMW': '1'}
+           'MASTER_PORT': _free_port(), 'DA_DP_RESERVE_CUS': '16', 'DA_SLICED_ADAMW': '1'}
     one = _run(str(tmp_path / 'one.pt'), 1, env)
     assert one['backend'] == 'nccl' and one['reducer_enabled'] and one['reserve_cus'] == 16 and one['sliced']
     rel = ((one['grad'] - single['grad']).norm() / single['grad'].norm()).item()
     assert rel < 1e-5, rel
     upd = ((one['after'] - single['after']).norm() / (single['after'] - single['before']).norm()).item()
     assert upd < 1e-2, upd
+
+
+def test_multi_gpu_defaults_change_only_the_summation_order(tmp_path):
+    """The shipped world > 1 defaults (AdamW slices behind the buckets on the side stream, 8 CUs reserved while buckets
+    are in flight) against the same two ranks with both knobs off: the reduced gradient may differ only by the fixed
+    summation order of the re-split weight-gradient grids, and the optimizer step must land on the same weights."""
+    on = _run(str(tmp_path / 'on.pt'), 2, {})
+    off = _run(str(tmp_path / 'off.pt'), 2, {'DA_DP_RESERVE_CUS': '0', 'DA_SLICED_ADAMW': '0'})
+    assert on['sliced'] and on['reserve_cus'] == 8 and not off['sliced'] and off['reserve_cus'] == 0
+    assert torch.equal(on['before'], off['before'])
+    rel = ((on['grad'] - off['grad']).norm() / off['grad'].norm()).item()
+    assert rel < 1e-5, rel
+    upd = ((on['after'] - off['after']).norm() / (off['after'] - off['before']).norm()).item()
+    assert upd < 1e-2, upd
+
+
+def test_bench_launches_its_own_ranks(dev):
+    """`python bench.py --gpus 2` with no torchrun environment must start its two ranks itself (the reference's
+    `composer run.py` spawns its ranks, README.md:86-93) and print rank 0's one JSON line.  Both ranks share GPU 0 over
+    gloo here; on a multi-GPU node the same command runs one rank per GPU over RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'HSA_ENABLE_IPC_MODE_LEGACY')}
+    env['DA_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--batch', '32', '--steps', '2',
+                        '--warmup', '1', '--no-secondary', '--no-cpu-baseline'], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 64 and out['value'] > 0
+    assert out['roofline']['traffic'] is None      # the committed PMC figure belongs to batch 256 per GPU only

@@ -196,3 +196,56 @@ def test_reserved_cus_are_held_only_while_buckets_are_in_flight_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def test_bench_spawns_its_own_ranks_without_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` with no torchrun environment: the parent must hand the same arguments to
+    `torch.distributed.run --nproc-per-node N` on 127.0.0.1 (the reference's `composer run.py` spawns its ranks itself,
+    README.md:86-93) and return the children's status, without any torch.cuda call of its own."""
+    import importlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen['cmd'], seen['env'] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+
+    def no_gpu(*a, **k):
+        raise AssertionError('the launching parent made a GPU call')
+
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    for fn in ('is_available', 'current_device', 'set_device', 'synchronize', 'init'):
+        monkeypatch.setattr(torch.cuda, fn, no_gpu)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    assert cmd[-6:] == ['--gpus', '4', '--steps', '3', '--warmup', '1'] and cmd[-7].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'     # set by importing the package, inherited by the ranks
+
+
+def test_reducer_abort_gives_the_reserved_cus_back(monkeypatch):
+    """An exception in backward must not leave da_set_option('reserve_cus') set process-wide."""
+    from diffusion_amd import parallel
+    calls = []
+    red = parallel.BucketedAllReducer(torch.zeros(4096), bucket_elems=1024)
+    monkeypatch.setattr(red, '_set_reserve', lambda r: (calls.append(r), setattr(red, '_reserved', r > 0)))
+    red.enabled, red.reserve_cus = True, 8
+    monkeypatch.setattr(red, '_exchange', lambda v: None)
+    red.begin()
+    red.ready(2048)
+    assert calls == [8] and red._reserved
+    red.abort()
+    assert calls == [8, 0] and not red._reserved and red.hi == 0
