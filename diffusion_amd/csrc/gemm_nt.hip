@@ -252,6 +252,7 @@ extern int g_nt_korder;  // gemm_nt_v2.hip
 extern int g_nt_persist;
 extern int g_reserve_cus;
 extern int g_nt_persist_conv;
+extern int g_nt_de;
 extern int g_grad_overwrite;
 extern int g_gn_resident, g_gn_resident_form, g_gn_resident_min_slab;  // norms.hip
 int da_usable_cus(int cus);
@@ -369,6 +370,10 @@ extern "C" int da_set_option(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_tn_variant")) {
     g_tn_variant = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_de")) {
+    g_nt_de = value;
     return DA_OK;
   }
   if (key && !strcmp(key, "gemm_nt_persist_conv")) {

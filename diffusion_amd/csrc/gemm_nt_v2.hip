@@ -35,6 +35,7 @@ int g_nt_persist = -1;  // da_set_option("gemm_nt_persist", n): resident workgro
 // instead, so that a CU taken by a collective does not push a whole-CU workgroup into a second round.  0 = whole chip.
 int g_reserve_cus = 0;
 int g_nt_persist_conv = 1;  // da_set_option("gemm_nt_persist_conv", 0 | 1): the persistent tile walk for 3x3 convolutions
+int g_nt_de = 1;            // da_set_option("gemm_nt_de", 0 | 1): direct (register -> HBM) epilogue where it applies (nt2_tile, DE)
 int da_usable_cus(int cus) {
   int n = cus - g_reserve_cus;
   return n < 32 ? 32 : n;
@@ -130,10 +131,23 @@ DEVINL void glds16(const void* gsrc, char* lds_dst) {
 // matrix-pipe cycles on MFMA issue alone and the step measures ~3,500.
 // PERSIST: the resident-workgroup tile walk with the next tile's first K-step requested ahead of the epilogue (LDS map below).
 // Always with EARLY; also - round 3 - for the 16-wave convolution form when a launch has more tiles than CUs.
-template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU, bool EARLY, int MF = 16, bool PERSIST = EARLY>
+// DE (round 4): DIRECT epilogue - the tile leaves the accumulators for HBM without the LDS strip exchange.  With the
+// transposed products (CT) a lane's four registers of a 16x16 tile are four consecutive columns of one output row; packed
+// to bf16 that is 8 bytes, and one v_permlane16_swap per dword between the tiles (i, j) and (i, j+1) turns them into 16
+// contiguous bytes per lane (lane rows q = lane >> 4: q even -> tile j, q odd -> tile j+1, columns 8*(q>>1)..+7), i.e. one
+// global_store_dwordx4 per tile pair covering 16 rows x 64 B.  No LDS traffic, no barrier, ~10 VALU per store: by the
+// round-2 clock stamps the strip epilogue of a K = 320 tile took 13.6 us (4 strips x (LDS write + barrier + ~45 VALU per
+// task + barrier)) against 10.2 us for its whole K loop, with the matrix pipe idle and the read stream dry - the K <= 640
+// linears ran at 3.1-3.4 TB/s of algorithmic bytes.  The residual is loaded in the same lane layout (16 B per lane, the
+// same shuffle backwards) in two halves of the row block, each into registers the K loop's fragments (first half) and the
+// first half's accumulators (second half) have just left; sums and roundings are those of the strip epilogue, bit for bit.
+// HASR: a residual is added (compile-time, so that the form without one carries none of its registers or branches).
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU, bool EARLY, int MF = 16, bool PERSIST = EARLY, bool DE = false,
+          bool HASR = false>
 DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
   constexpr int NW = WM * WN;
-  constexpr bool CT = NT2_CT && !EARLY && MF == 16 && GEGLU == 0;  // transposed products, see NT2_CT
+  constexpr bool CT = MF == 16 && GEGLU == 0 && ((NT2_CT && !EARLY) || DE);  // transposed products, see NT2_CT
+  static_assert(!DE || (MF == 16 && GEGLU == 0 && ((NT % 2) == 0 || (MT % 2) == 0)), "direct epilogue: 16x16 tiles in pairs");
   constexpr int V2_BM = MF * MT * WM, V2_BK = BK;
   static_assert((NW == 16 || NW == 8 || NW == 4) && (BK == 64 || BK == 32), "wave grid");
   static_assert(MF == 16 || (MF == 32 && GEGLU == 0 && BK == 64), "MFMA shape");
@@ -251,7 +265,11 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
       // base A + c0 plus a 32-bit per-lane BYTE offset (the host checks M * lda * 2 < 4 GiB), the SGPR-base addressing form
       // of the load: one VGPR per row group instead of a 64-bit pointer and a mask.  Rows past M read row 0: their
       // products land in rows the epilogue never stores.
+#ifdef NT2_EXP_AHOT     // timing-only build: every tile reads the first 256 rows of A (L2-resident)
+      aoff[j] = (unsigned)(row) * (unsigned)(p.lda * 2) + (lchunk ^ swz_key<BK>(row)) * 16;
+#else
       aoff[j] = (unsigned)(mval ? m : 0) * (unsigned)(p.lda * 2) + (lchunk ^ swz_key<BK>(row)) * 16;
+#endif
       continue;
     }
     const int mm = mval ? m : 0;
@@ -500,6 +518,107 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
 
   // the epilogue of tile (m0e, n0e, tne, splite) with its bias row in LDS buffer bbuf
   auto epilogue = [&](const int m0e, const int n0e, const int tne, const int splite, const int bbuf) {
+  if constexpr (DE) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    constexpr int NPJ = NT / 2;                    // column pairs (i, 2*pj), (i, 2*pj+1) per 16-row strip
+    constexpr bool ODD = (NT & 1) != 0;            // odd NT: the last column tiles pair up over rows, (i-1, NT-1), (i, NT-1), i odd
+    constexpr int IH = ODD ? ((MT / 2 + 1) / 2) * 2 : (MT + 1) / 2;  // strips of the first half (whole row pairs when ODD)
+    const int ln = fresh_lane();
+    char* const cb = reinterpret_cast<char*>(p.C);
+    const char* const rb = reinterpret_cast<const char*>(p.R);
+    // (row, column) of this lane's 16 bytes inside the tile: column pair pj of strip i / the odd column's row pair ending at strip i
+    const int lrow = wm * (16 * MT) + (ln & 15), lq = (ln >> 4) & 1, lcol = wn * (16 * NT) + 8 * (ln >> 5);
+    auto row_of = [&](int i) { return m0e + lrow + i * 16; };
+    auto col_of = [&](int pj) { return n0e + lcol + 32 * pj + 16 * lq; };
+    auto row5_of = [&](int i) { return m0e + lrow + (i - 1 + lq) * 16; };
+    const int col5 = n0e + lcol + 16 * (NT - 1);
+    u32x4 rin[MT][NPJ > 0 ? NPJ : 1], rin5[MT];
+    // residual rows of strips [i_lo, i_hi): rows / columns past the matrix are clamped, not predicated (what they feed is
+    // never stored; a branch per load would make the compiler wait vmcnt(0) per use beside the LDS-DMA requests in flight)
+    auto fetch = [&](const int i_lo, const int i_hi) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (i < i_lo || i >= i_hi) continue;
+        const unsigned mo = (unsigned)min(row_of(i), p.M - 1) * (unsigned)(p.ldr * 2);
+#pragma unroll
+        for (int pj = 0; pj < NPJ; ++pj)
+          rin[i][pj] = *reinterpret_cast<const u32x4*>(rb + (mo + (unsigned)min(col_of(pj), p.N - 8) * 2u));
+        if constexpr (ODD) {
+          if (i & 1)
+            rin5[i] = *reinterpret_cast<const u32x4*>(rb + ((unsigned)min(row5_of(i), p.M - 1) * (unsigned)(p.ldr * 2) +
+                                                            (unsigned)min(col5, p.N - 8) * 2u));
+        }
+      }
+    };
+    // the 16 bytes of a tile pair (a, b): [+ row bias] [+ residual] -> bf16 -> lane shuffle
+    auto finish = [&](accv_t a, accv_t b, const u32x4 r, const int ma, const int mb, const int na, const int nb) {
+      if (p.rowbias) {  // per-image row bias (the time-embedding projection behind a ResnetBlock2D's first convolution)
+        const int ia = (PERSIST && !EARLY) ? (int)fdiv((unsigned)min(ma, p.M - 1), p.div_hw) : min(ma, p.M - 1) / HWo;
+        const int ib = (PERSIST && !EARLY) ? (int)fdiv((unsigned)min(mb, p.M - 1), p.div_hw) : min(mb, p.M - 1) / HWo;
+        const bf16x4 ra = *reinterpret_cast<const bf16x4*>(p.rowbias + (long)ia * p.ldrb + min(na, p.N - 4));
+        const bf16x4 rb4 = *reinterpret_cast<const bf16x4*>(p.rowbias + (long)ib * p.ldrb + min(nb, p.N - 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] += bf2f(ra[e]);
+          b[e] += bf2f(rb4[e]);
+        }
+      }
+      if constexpr (HASR) {
+        // the store shuffle backwards: dwords (0, 2) and (1, 3) swap back to (tile a, tile b) x (columns 0-1, columns 2-3)
+        const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(r[0], r[2], false, false);
+        const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(r[1], r[3], false, false);
+        a[0] += __builtin_bit_cast(float, s0[0] << 16);
+        a[1] += __builtin_bit_cast(float, s0[0] & 0xffff0000u);
+        a[2] += __builtin_bit_cast(float, s1[0] << 16);
+        a[3] += __builtin_bit_cast(float, s1[0] & 0xffff0000u);
+        b[0] += __builtin_bit_cast(float, s0[1] << 16);
+        b[1] += __builtin_bit_cast(float, s0[1] & 0xffff0000u);
+        b[2] += __builtin_bit_cast(float, s1[1] << 16);
+        b[3] += __builtin_bit_cast(float, s1[1] & 0xffff0000u);
+      }
+      bf16x2 a0, a1, b0, b1;
+      a0[0] = f2bf(a[0]); a0[1] = f2bf(a[1]); a1[0] = f2bf(a[2]); a1[1] = f2bf(a[3]);
+      b0[0] = f2bf(b[0]); b0[1] = f2bf(b[1]); b1[0] = f2bf(b[2]); b1[1] = f2bf(b[3]);
+      const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0), false, false);
+      const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1), false, false);
+      return u32x4{s0[0], s1[0], s0[1], s1[1]};
+    };
+    const int aq = (ln >> 4) * 4;  // first column of this lane's accumulator quad inside a 16-column tile
+    if constexpr (HASR) fetch(0, IH);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if constexpr (HASR) {
+        if (i == IH) fetch(IH, MT);
+      }
+      const int m = row_of(i);
+      const int ma = m0e + wm * (16 * MT) + i * 16 + (ln & 15);  // the accumulators' own row (before the shuffle)
+#pragma unroll
+      for (int pj = 0; pj < NPJ; ++pj) {
+        const int n = col_of(pj);
+        const int na = n0e + wn * (16 * NT) + 32 * pj + aq;
+        const u32x4 o = finish(acc[i][2 * pj], acc[i][2 * pj + 1], rin[i][pj], ma, ma, na, na + 16);
+#ifdef NT2_EXP_NOSTORE  // timing-only build (tools/build_alt.sh): the tile is computed and packed, nothing is stored
+        asm volatile("" ::"v"(o));
+#else
+        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(cb + ((unsigned)m * (unsigned)(p.ldc * 2) + (unsigned)n * 2u)) = o;
+#endif
+      }
+      if constexpr (ODD) {
+        if (i & 1) {
+          const int m5 = row5_of(i);
+          const int na = n0e + wn * (16 * NT) + 16 * (NT - 1) + aq;
+          const u32x4 o = finish(acc[i - 1][NT - 1], acc[i][NT - 1], rin5[i], ma - 16, ma, na, na);
+#ifdef NT2_EXP_NOSTORE
+          asm volatile("" ::"v"(o));
+#else
+          if (m5 < p.M && col5 < p.N) *reinterpret_cast<u32x4*>(cb + ((unsigned)m5 * (unsigned)(p.ldc * 2) + (unsigned)col5 * 2u)) = o;
+#endif
+        }
+      }
+    }
+    STAMP(4);
+    return;
+  }
   const float* bias_lds = reinterpret_cast<const float*>(smem + BIAS_OFF + bbuf * (BN * 4));
   float* const strips = reinterpret_cast<float*>(smem + STRIP_OFF);
   const int el = fresh_lane();
@@ -769,10 +888,11 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
 // list with stride gridDim.x inside nt2_tile, requesting the next tile's first K-step before the epilogue of the current
 // one, so neither that load nor the epilogue's stores are waited for between tiles, and no workgroup is torn down and
 // re-dispatched per tile.
-template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU = 0, bool EARLY = false, int MF = 16, bool PERSIST = EARLY>
+template <int MT, int NT, int WM, int WN, int BK, bool UPS, int GEGLU = 0, bool EARLY = false, int MF = 16, bool PERSIST = EARLY, bool DE = false,
+          bool HASR = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : 2)) void gemm_nt2_kernel(GemmNT2Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY, MF, PERSIST>(p, blockIdx.x, smem);
+  nt2_tile<MT, NT, WM, WN, BK, UPS, GEGLU, EARLY, MF, PERSIST, DE, HASR>(p, blockIdx.x, smem);
 }
 
 // split-K finalize: out[m][n] = alpha * sum_s slab[s][m][n] + bias[n] + rowbias[image(m)][n] + R[m][n]
@@ -869,6 +989,32 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3((int)blocks), dim3(256), 0, stream, p, (const float*)ws);
     DA_CHECK_LAUNCH();
     return DA_OK;
+  }
+  if constexpr (MF == 16 && !EARLY && ((NT % 2) == 0 || (MT % 2) == 0)) {
+    // direct epilogue (see nt2_tile, DE) - convolution forms only: on the short-K linears it measured -2...+2 % without a
+    // residual and -7...-13 % with one (its 16-row x 64-byte residual reads against the strip path's whole 640-byte rows;
+    // profiles/r04_ab_nt_de.txt), because there the tile is paced by the DRAIN of its stores, not by the epilogue's
+    // instructions (a timing-only build without the stores ran 95 -> 56 us at 262144 x 320 x 320)
+    // direct epilogue (see nt2_tile, DE): bf16 output, alpha 1 (bias already in the accumulators), 16-byte aligned rows,
+    // everything inside 32-bit byte offsets
+    const bool de = g_nt_de && !p.out_fp32 && p.alpha == 1.0f && (p.N % 8) == 0 && (p.ldc % 8) == 0 && !((uintptr_t)p.C & 15) &&
+                    (long)p.M * p.ldc * 2 < (1L << 32) &&
+                    (!p.R || ((p.ldr % 8) == 0 && !((uintptr_t)p.R & 15) && (long)p.M * p.ldr * 2 < (1L << 32))) &&
+                    (!p.rowbias || ((p.ldrb % 4) == 0 && !((uintptr_t)p.rowbias & 7)));
+    if (de) {
+      static unsigned long long attr_done_de[2] = {0, 0};
+      if (p.R) {
+        if (da_ensure_dyn_smem((const void*)gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF, PERSIST, true, true>, SMEM, &attr_done_de[1]) != DA_OK)
+          return DA_ERR_LAUNCH;
+        hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF, PERSIST, true, true>), dim3(grid), dim3(NTHREADS), SMEM, stream, p);
+      } else {
+        if (da_ensure_dyn_smem((const void*)gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF, PERSIST, true, false>, SMEM, &attr_done_de[0]) != DA_OK)
+          return DA_ERR_LAUNCH;
+        hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF, PERSIST, true, false>), dim3(grid), dim3(NTHREADS), SMEM, stream, p);
+      }
+      DA_CHECK_LAUNCH();
+      return DA_OK;
+    }
   }
   hipLaunchKernelGGL((gemm_nt2_kernel<MT, NT, WM, WN, BK, UPS, 0, EARLY, MF, PERSIST>), dim3(grid), dim3(NTHREADS), SMEM, stream, p);
   DA_CHECK_LAUNCH();

@@ -205,6 +205,77 @@ def test_gemm_nt_persistent_tile_walk(ops, dev, grid):
     check(ref[2], h[:, :inner] * F.gelu(h[:, inner:]), what='persistent geglu')
 
 
+@pytest.mark.parametrize('variant', [12, 10, 11, 14, 5, 4, 18])
+def test_gemm_nt_direct_epilogue_equals_strip_epilogue(ops, dev, variant):
+    """The direct epilogue (accumulators -> bf16 -> v_permlane16_swap -> 16-byte stores, residual fetched in the same lane
+    layout; da_set_option('gemm_nt_de', 1), the default) against the LDS strip epilogue it replaces (0): same sums, same
+    roundings, so every form must agree BIT FOR BIT - linears (persistent walk), 3x3 convolutions with the per-image row
+    bias and a residual (one tile per workgroup, and the persistent convolution walk at a forced grid), stride 2, its
+    dgrad, the fused upsample, ragged row / column tails, strided views, an in-place residual."""
+    ops.set_option('gemm_nt_variant', variant)
+
+    def all_forms():
+        outs = []
+        M, N, K = 1500, 968, 320    # ragged in both directions
+        A = rnd(M, K, dev=dev, seed=1).to(BF); W = rnd(N, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
+        bias = rnd(N, dev=dev, seed=3); R = rnd(M, N, dev=dev, seed=4).to(BF)
+        for b_, r_ in ((bias, R), (None, None), (bias, None), (None, R)):
+            o = torch.empty(M, N, device=dev, dtype=BF)
+            ops.gemm_nt(A, W, o, ops.Geom.linear(M), bias=b_, residual=r_)
+            outs.append(o)
+        acc = R.clone()     # in-place residual: out = A W^T + out
+        ops.gemm_nt(A, W, acc, ops.Geom.linear(M), residual=acc)
+        outs.append(acc)
+        check(outs[0], A.float() @ W.float().t() + bias + R.float(), what='linear bias+res')
+        check(outs[4], A.float() @ W.float().t() + R.float(), what='linear in-place res')
+        B, H, Wd, C, Co = 5, 12, 12, 64, 648
+        x = rnd(B, C, H, Wd, dev=dev, seed=1).to(BF)
+        w = rnd(Co, C, 3, 3, dev=dev, seed=2, scale=(9 * C)**-0.5).to(BF)
+        rb = rnd(B, Co, dev=dev, seed=4).to(BF); cb = rnd(Co, dev=dev, seed=5)
+        Rc = rnd(B * H * Wd, Co, dev=dev, seed=6).to(BF)
+        for grid in (-1, 3):   # 3 resident workgroups: the persistent convolution walk where the form has one
+            ops.set_option('gemm_nt_persist', grid)
+            o = torch.empty(B * H * Wd, Co, device=dev, dtype=BF)
+            ops.gemm_nt(nhwc(x), w_ohwi(w), o, ops.Geom.conv(B, H, Wd), bias=cb, rowbias=rb, residual=Rc)
+            outs.append(o)
+        ops.set_option('gemm_nt_persist', -1)
+        ref = F.conv2d(x.float(), w.float(), cb, padding=1) + rb.float()[:, :, None, None]
+        check(from_nhwc(outs[5], B, H, Wd), ref + from_nhwc(Rc.float(), B, H, Wd), what='conv3x3 rowbias+res')
+        o2 = torch.empty(B * (H // 2) * (Wd // 2), Co, device=dev, dtype=BF)
+        ops.gemm_nt(nhwc(x), w_ohwi(w), o2, ops.Geom.down(B, H, Wd), bias=cb)
+        outs.append(o2)
+        o4 = torch.empty(B * 4 * H * Wd, Co, device=dev, dtype=BF)
+        ops.gemm_nt(nhwc(x), w_ohwi(w), o4, ops.Geom.up(B, H, Wd), residual=rnd(B * 4 * H * Wd, Co, dev=dev, seed=7).to(BF))
+        outs.append(o4)
+        Cop = 256
+        dy3 = rnd(B, Cop, H // 2, Wd // 2, dev=dev, seed=8).to(BF)
+        w3 = rnd(Cop, C, 3, 3, dev=dev, seed=9, scale=(9 * C)**-0.5).to(BF)
+        wt = torch.empty(C, 9 * Cop, device=dev, dtype=BF)
+        ops.transpose_weight(w_ohwi(w3), wt, Cop, 9, C)
+        dx = torch.empty(B * H * Wd, C, device=dev, dtype=BF)
+        ops.gemm_nt(nhwc(dy3), wt, dx, ops.Geom.down_dgrad(B, H, Wd))
+        outs.append(dx)
+        buf = rnd(600, 3 * 64, dev=dev, seed=5).to(BF)
+        Wl = rnd(160, 64, dev=dev, seed=6, scale=0.1).to(BF)
+        ob = torch.zeros(600, 400, device=dev, dtype=BF)
+        ops.gemm_nt(buf[:, 64:128], Wl, ob[:, 80:240], ops.Geom.linear(600), residual=buf[:, 8:168])
+        outs.append(ob)
+        assert (ob[:, :80] == 0).all() and (ob[:, 240:] == 0).all()
+        return outs
+
+    try:
+        ops.set_option('gemm_nt_de', 0)
+        ref = all_forms()
+        ops.set_option('gemm_nt_de', 1)
+        got = all_forms()
+    finally:
+        ops.set_option('gemm_nt_de', 1)
+        ops.set_option('gemm_nt_persist', -1)
+        ops.set_option('gemm_nt_variant', 0)
+    for i, (r, g_) in enumerate(zip(ref, got)):
+        assert torch.equal(r, g_), f'form {i}: {(r.float() - g_.float()).abs().max().item()}'
+
+
 @pytest.mark.parametrize('variant', [4, 5, 10, 11, 12, 14, 15, 16, 18])
 def test_gemm_nt_v2_variants(ops, dev, variant):
     """The 256x(128|160) LDS-DMA kernel forced on: linear + every conv mode, ragged M / N tails, fused epilogue."""

@@ -67,6 +67,10 @@ def run(old, new, what):
         k_, v_ = kv.split('=')
         old.da_set_option.argtypes = [_ct.c_char_p, _ct.c_int]
         assert old.da_set_option(k_.encode(), int(v_)) == 0, kv
+    for kv in filter(None, os.environ.get('DA_AB_NEW_OPTS', '').split(',')):   # the same for the candidate
+        k_, v_ = kv.split('=')
+        new.da_set_option.argtypes = [_ct.c_char_p, _ct.c_int]
+        assert new.da_set_option(k_.encode(), int(v_)) == 0, kv
     dev = torch.device('cuda')
     BF = torch.bfloat16
     st = torch.cuda.current_stream().cuda_stream
@@ -138,8 +142,11 @@ def run(old, new, what):
         ws = torch.empty(32 * 1024 * 1024, device=dev)
         # (pixels per image, N, Cin, H, W, ksize, residual)
         shapes = [(1024, 320, 320, 32, 32, 3, 0), (1024, 320, 320, 32, 32, 3, 1), (256, 640, 640, 16, 16, 3, 0), (64, 1280, 1280, 8, 8, 3, 1),
-                  (16, 1280, 1280, 4, 4, 3, 0), (1024, 320, 960, 32, 32, 3, 0), (1024, 320, 320, 1, 1, 1, 1), (1024, 960, 320, 1, 1, 1, 0),
-                  (256, 640, 640, 1, 1, 1, 1), (64, 1280, 1280, 1, 1, 1, 1), (1024, 320, 1280, 1, 1, 1, 1), (256, 640, 2560, 1, 1, 1, 1)]
+                  (16, 1280, 1280, 4, 4, 3, 0), (1024, 320, 960, 32, 32, 3, 0), (1024, 320, 320, 1, 1, 1, 1), (1024, 320, 320, 1, 1, 1, 0),
+                  (1024, 960, 320, 1, 1, 1, 0), (256, 640, 640, 1, 1, 1, 1), (256, 640, 640, 1, 1, 1, 0), (64, 1280, 1280, 1, 1, 1, 1),
+                  (1024, 320, 1280, 1, 1, 1, 1), (256, 640, 2560, 1, 1, 1, 1)]
+        if os.environ.get('DA_AB_ONLY_LINEAR'):
+            shapes = [s_ for s_ in shapes if s_[5] == 1]
         for hw, N, Cin, H, W, ks, res in shapes:
             M = Bt * hw
             a = torch.randn(M, Cin, device=dev).to(BF); w = (torch.randn(N, ks * ks * Cin, device=dev) * 0.05).to(BF)
@@ -156,7 +163,7 @@ def run(old, new, what):
             print(f'nt M={M} N={N} K={ks * ks * Cin} k{ks} res{res}: {ta:7.0f} -> {tb:7.0f} us ({fl / tb / 1e6:5.0f} TF/s, {100 * (ta / tb - 1):+5.1f} %) '
                   f'equal {torch.equal(outs[0], outs[1])}', flush=True)
             del a, w, r, outs
-        for hw, C in ((1024, 320), (256, 640), (64, 1280)):   # fused GEGLU forward / backward of the feed-forward
+        for hw, C in (() if os.environ.get('DA_AB_ONLY_LINEAR') else ((1024, 320), (256, 640), (64, 1280))):   # fused GEGLU forward / backward of the feed-forward
             M = Bt * hw
             inner = 4 * C
             a = torch.randn(M, C, device=dev).to(BF); w = (torch.randn(2 * inner, C, device=dev) * 0.05).to(BF)
