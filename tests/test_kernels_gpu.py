@@ -276,6 +276,49 @@ def test_gemm_nt_direct_epilogue_equals_strip_epilogue(ops, dev, variant):
         assert torch.equal(r, g_), f'form {i}: {(r.float() - g_.float()).abs().max().item()}'
 
 
+@pytest.mark.parametrize('grid', [-1, 1, 5])
+@pytest.mark.parametrize('M,N,K', [(1500, 968, 320), (2048, 320, 384), (1111, 640, 640), (4096, 2560, 1024)])
+def test_gemm_nt_streaming_form_equals_tiled_form(ops, dev, grid, M, N, K):
+    """gemm_nt_v3.hip (short-K linears: 128 x 320 tiles, the previous tile's stores and this tile's residual loads issued one
+    piece per K-step behind counted vmcnt waits; da_set_option('gemm_nt_stream', 2) = wherever eligible) against the tiled
+    form it replaces (0): same sums, same roundings -> BIT-identical, with / without bias and residual, ragged row and
+    column tails, an in-place residual, strided views, and with a forced grid of 1 / 5 resident workgroups (every workgroup
+    then walks many tiles and the deferred stores / prefetch cursors cross many tile boundaries)."""
+    A = rnd(M, K, dev=dev, seed=1).to(BF); W = rnd(N, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
+    bias = rnd(N, dev=dev, seed=3); R = rnd(M, N, dev=dev, seed=4).to(BF)
+    wide = rnd(M, N + 64, dev=dev, seed=5).to(BF)
+
+    def run():
+        outs = []
+        for b_, r_ in ((bias, R), (None, None), (bias, None), (None, R)):
+            o = torch.full((M, N), 7.0, device=dev, dtype=BF)
+            ops.gemm_nt(A, W, o, ops.Geom.linear(M), bias=b_, residual=r_)
+            outs.append(o)
+        acc = R.clone()
+        ops.gemm_nt(A, W, acc, ops.Geom.linear(M), bias=bias, residual=acc)     # in place
+        outs.append(acc)
+        buf = torch.zeros(M, N + 64, device=dev, dtype=BF)
+        ops.gemm_nt(A, W, buf[:, 32:32 + N], ops.Geom.linear(M), residual=wide[:, 16:16 + N])   # strided C and R
+        outs.append(buf)
+        return outs
+
+    try:
+        ops.set_option('gemm_nt_stream', 0)
+        ref = run()
+        ops.set_option('gemm_nt_stream', 2)
+        ops.set_option('gemm_nt_persist', grid)
+        got = run()
+    finally:
+        ops.set_option('gemm_nt_persist', -1)
+        ops.set_option('gemm_nt_stream', 0)
+    for i, (r, g_) in enumerate(zip(ref, got)):
+        assert torch.equal(r, g_), f'form {i}: max |diff| {(r.float() - g_.float()).abs().max().item()}'
+    full = A.float() @ W.float().t()
+    check(got[0], full + bias + R.float(), what='streaming linear bias+res')
+    check(got[1], full, what='streaming linear plain')
+    assert (got[5][:, :32] == 0).all() and (got[5][:, 32 + N:] == 0).all()
+
+
 @pytest.mark.parametrize('variant', [4, 5, 10, 11, 12, 14, 15, 16, 18])
 def test_gemm_nt_v2_variants(ops, dev, variant):
     """The 256x(128|160) LDS-DMA kernel forced on: linear + every conv mode, ragged M / N tails, fused epilogue."""
