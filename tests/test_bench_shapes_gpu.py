@@ -304,3 +304,161 @@ def test_linear_input_of_4_gib_takes_the_pointer_form(ops, dev):
     for lo in (0, (1 << 20) - 128, M - 512):      # first rows, rows straddling 2 GiB, the last rows (past 4 GiB)
         ref = A[lo:lo + 512].float() @ W.float().t() + bias
         check_blocks(out[lo:lo + 512], ref, what=f'rows {lo}..')
+
+
+def _record(case, **kv):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from parity_margins import record
+    record(case, **kv)
+
+
+def conv3x3_strided_ref(x, w, B, H, W, stride=1, up=False):
+    """fp32 3x3 convolution (pad 1) of x [B*H*W, C] by nine shifted matmuls: stride 2, or over the nearest-2x upsampled
+    image (the fused mode 3 gather)."""
+    C, N = x.shape[1], w.shape[0]
+    img = x.float().reshape(B, H, W, C)
+    if up:
+        img = img.repeat_interleave(2, 1).repeat_interleave(2, 2)
+        H, W = 2 * H, 2 * W
+    xp = F.pad(img, (0, 0, 1, 1, 1, 1))
+    Ho, Wo = H // stride, W // stride
+    w4 = w.float().reshape(N, 3, 3, C)
+    out = torch.zeros(B * Ho * Wo, N, device=x.device)
+    for r in range(3):
+        for s in range(3):
+            out += xp[:, r:r + H:stride, s:s + W:stride, :].reshape(-1, C) @ w4[:, r, s, :].t()
+    return out
+
+
+@pytest.mark.parametrize('B,H,C', [(256, 32, 320), (256, 16, 640), (64, 32, 640)])
+def test_downsample_conv_and_its_dgrad_at_bench_shape(ops, dev, B, H, C):
+    """Gather modes 1 (stride-2 downsampler) and 2 (its dgrad, 3 of 4 taps structurally zero) at the bench batch: the
+    320@32->16 and 640@16->8 downsamplers of the 256-px step, 640@32->16 of the 512-px step (batch 64)."""
+    M_in, M_out = B * H * H, B * (H // 2) * (H // 2)
+    x = rnd(M_in, C, dev=dev, seed=1).to(BF)
+    w = rnd(C, 9 * C, dev=dev, seed=2, scale=(9 * C)**-0.5).to(BF)
+    bias = rnd(C, dev=dev, seed=3)
+    out = torch.empty(M_out, C, device=dev, dtype=BF)
+    ops.gemm_nt(x, w, out, ops.Geom.down(B, H, H), bias=bias)
+    ref = conv3x3_strided_ref(x, w, B, H, H, stride=2) + bias
+    check_blocks(out, ref, what='downsample fwd')
+    _record(f'bench_shape_down_{C}@{H}_b{B}', fwd_rel_l2=rel_l2(out, ref))
+    del ref
+    dy = rnd(M_out, C, dev=dev, seed=4).to(BF)
+    wt = torch.empty(C, 9 * C, device=dev, dtype=BF)
+    ops.transpose_weight(w, wt, C, 9, C)
+    dx = torch.empty(M_in, C, device=dev, dtype=BF)
+    ops.gemm_nt(dy, wt, dx, ops.Geom.down_dgrad(B, H, H))
+    xr = x.float().requires_grad_(True)
+    conv3x3_strided_ref(xr, w, B, H, H, stride=2).backward(dy.float())
+    check_blocks(dx, xr.grad, what='downsample dgrad')
+    _record(f'bench_shape_down_{C}@{H}_b{B}', dgrad_rel_l2=rel_l2(dx, xr.grad))
+    g = ops.Geom.down(B, H, H)
+    dW = torch.zeros(C, 9 * C, device=dev)
+    ops.gemm_tn_wgrad(dy, x, dW, g)
+    wr = w.float().requires_grad_(True)
+    conv3x3_strided_ref(x, wr, B, H, H, stride=2).backward(dy.float())
+    check_blocks(dW, wr.grad, tol=2e-3, rows=64, what='downsample wgrad')
+
+
+@pytest.mark.parametrize('B,H,C', [(256, 16, 640), (256, 8, 1280)])
+def test_upsample_fused_conv_at_bench_shape(ops, dev, B, H, C):
+    """Gather mode 3 (3x3 convolution over the nearest-2x upsampled image, never materialised): the 640@16->32 upsampler is
+    the longest single launch of the 256-px step (gemm_nt2<..., UPS = true>)."""
+    M_in, M_out = B * H * H, B * 4 * H * H
+    x = rnd(M_in, C, dev=dev, seed=1).to(BF)
+    w = rnd(C, 9 * C, dev=dev, seed=2, scale=(9 * C)**-0.5).to(BF)
+    bias = rnd(C, dev=dev, seed=3)
+    assert nt_variant(ops, M_out, C, 9 * C, C) == 12
+    out = torch.empty(M_out, C, device=dev, dtype=BF)
+    ops.gemm_nt(x, w, out, ops.Geom.up(B, H, H), bias=bias)
+    ref = conv3x3_strided_ref(x, w, B, H, H, up=True) + bias
+    check_blocks(out, ref, what='upsample-fused conv fwd')
+    _record(f'bench_shape_up_{C}@{H}_b{B}', fwd_rel_l2=rel_l2(out, ref))
+    del ref
+    dy = rnd(M_out, C, dev=dev, seed=4).to(BF)
+    dW = torch.zeros(C, 9 * C, device=dev)
+    ops.gemm_tn_wgrad(dy, x, dW, ops.Geom.up(B, H, H))
+    wr = w.float().requires_grad_(True)
+    conv3x3_strided_ref(x, wr, B, H, H, up=True).backward(dy.float())
+    check_blocks(dW, wr.grad, tol=2e-3, rows=64, what='upsample-fused wgrad')
+
+
+def test_splitk_conv_at_the_4x4_level_at_bench_shape(ops, dev):
+    """conv 1280 -> 1280 at 4x4, batch 256: M = 4,096 rows = 16 row tiles x 4 column tiles for 256 CUs, so the dispatcher
+    splits K = 11,520 over several workgroups per tile (fp32 slabs + finalize kernel)."""
+    B, H, C = 256, 4, 1280
+    M = B * H * H
+    x = rnd(M, C, dev=dev, seed=1).to(BF)
+    w = rnd(C, 9 * C, dev=dev, seed=2, scale=(9 * C)**-0.5).to(BF)
+    bias = rnd(C, dev=dev, seed=3); rb = rnd(B, C, dev=dev, seed=4).to(BF); res = rnd(M, C, dev=dev, seed=5).to(BF)
+    assert nt_variant(ops, M, C, 9 * C, C) == 12
+    out = torch.empty(M, C, device=dev, dtype=BF)
+    ops.gemm_nt(x, w, out, ops.Geom.conv(B, H, H), bias=bias, rowbias=rb, residual=res)
+    ref = conv3x3_ref(x, w, B, H, H) + bias + rb.float().repeat_interleave(H * H, 0) + res.float()
+    check_blocks(out, ref, what='split-K conv 1280@4x4')
+    _record('bench_shape_splitk_4096x1280x11520', fwd_rel_l2=rel_l2(out, ref))
+
+
+@pytest.mark.parametrize('B,H,Nq,Nk', [(256, 5, 1024, 77), (256, 20, 64, 64), (256, 10, 256, 256), (256, 10, 256, 77),
+                                       (256, 20, 64, 77)])
+def test_attention_at_bench_batch(ops, dev, B, H, Nq, Nk):
+    """Cross-attention against the 77 text tokens and the low-resolution self-attention levels at batch 256 (the (image, head,
+    block) grids of the step; the 1,024-token self-attention at batch 8 is in test_attention_at_bench_shape)."""
+    C = H * 64
+    scale = 0.125
+    if Nq == Nk:
+        qkv = rnd(B * Nq, 3 * C, dev=dev, seed=1).to(BF)
+        q2, k2, v2 = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    else:
+        q2 = rnd(B * Nq, C, dev=dev, seed=1).to(BF)
+        kv = rnd(B * Nk, 2 * C, dev=dev, seed=2).to(BF)
+        k2, v2 = kv[:, :C], kv[:, C:]
+    do = rnd(B * Nq, C, dev=dev, seed=4).to(BF)
+    qf, kf, vf = (t.float().reshape(B, n, C).requires_grad_(True) for t, n in ((q2, Nq), (k2, Nk), (v2, Nk)))
+    ref = _attn_ref(qf, kf, vf, H, scale)
+    ref.backward(do.float().reshape(B, Nq, C))
+    ref = ref.detach()
+    O = torch.empty(B * Nq, C, device=dev, dtype=BF)
+    L2 = torch.empty(B * H * Nq, device=dev)
+    ops.attn_fwd(q2, k2, v2, O, L2, B, H, Nq, Nk, scale)
+    check_blocks(O, ref.reshape(B * Nq, C), tol=6e-3, what='attn fwd')
+    dQ = torch.empty_like(O)
+    dKV = torch.empty(B * Nk, 2 * C, device=dev, dtype=BF)
+    Delta = torch.empty_like(L2)
+    ops.attn_bwd(q2, k2, v2, O, do, L2, Delta, dQ, dKV[:, :C], dKV[:, C:], B, H, Nq, Nk, scale)
+    check_blocks(dQ, qf.grad.reshape(B * Nq, C), tol=1.2e-2, what='attn dQ')
+    rows = 256 if Nk >= 256 else Nk
+    check_blocks(dKV[:, :C], kf.grad.reshape(B * Nk, C), tol=1.2e-2, rows=rows, what='attn dK')
+    check_blocks(dKV[:, C:], vf.grad.reshape(B * Nk, C), tol=1.2e-2, rows=rows, what='attn dV')
+    _record(f'bench_shape_attn_b{B}_h{H}_{Nq}x{Nk}', fwd_rel_l2=rel_l2(O, ref.reshape(B * Nq, C)),
+            dq_rel_l2=rel_l2(dQ, qf.grad.reshape(B * Nq, C)), dk_rel_l2=rel_l2(dKV[:, :C], kf.grad.reshape(B * Nk, C)),
+            dv_rel_l2=rel_l2(dKV[:, C:], vf.grad.reshape(B * Nk, C)))
+
+
+@pytest.mark.parametrize('M,C', [(262144, 320), (65536, 640), (16384, 1280)])
+def test_layernorm_at_bench_shape(ops, dev, M, C):
+    """LayerNorm forward / backward at the token counts of the step (ln_fwd5 / ln_bwd5: several rows per wave) against fp32
+    autograd, whole tensor and worst 256-row block; dgamma / dbeta are fixed-order column sums over up to 262,144 rows."""
+    x = rnd(M, C, dev=dev, seed=1, scale=2.0).to(BF) + 0.3
+    dy = rnd(M, C, dev=dev, seed=2).to(BF)
+    gamma = rnd(C, dev=dev, seed=3) * 0.2 + 1.0
+    beta = rnd(C, dev=dev, seed=4) * 0.2
+    y = torch.empty_like(x); dx = torch.empty_like(x)
+    st = torch.empty(M * 2, device=dev)
+    ops.layernorm_fwd(x, y, gamma, beta, st, 1e-5)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    check_blocks(y, ref.detach(), what='layernorm fwd')
+    ref.backward(dy.float())
+    dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    scratch = torch.empty(1024 * C * 2, device=dev)
+    ops.layernorm_bwd(x, dy, None, dx, gamma, st, dg, db, scratch)
+    check_blocks(dx, xr.grad, what='layernorm dx')
+    assert rel_l2(dg, gr.grad) < 3e-3, rel_l2(dg, gr.grad)
+    assert rel_l2(db, br.grad) < 3e-3, rel_l2(db, br.grad)
+    _record(f'bench_shape_layernorm_{M}x{C}', fwd_rel_l2=rel_l2(y, ref.detach()), dx_rel_l2=rel_l2(dx, xr.grad),
+            dgamma_rel_l2=rel_l2(dg, gr.grad), dbeta_rel_l2=rel_l2(db, br.grad))

@@ -283,3 +283,59 @@ def test_two_identical_steps_give_bitwise_equal_gradients(full, dev):
         bad = [k for k, p in model.unet.named_parameters() if not torch.equal(p.grad, ref[k] * rep)]
         assert not bad, (rep, len(bad), bad[:5])
     model.unet.zero_grad()
+
+
+# bounds of the bench-batch property test below: <= 2 x the margins measured on MI355X (profiles/r04_parity_margins.json:
+# |loss difference| 1.5e-6 / 1.4e-5, flat-gradient rel-L2 9.3e-4 / 8.8e-4, per-tensor norm ratio 0.99884 .. 1.00055, whole
+# gradient 0.99997 .. 1.00003 at 32^2 x 256 / 64^2 x 64)
+TOL_BATCH = {'loss_abs': 3e-5, 'grad_rel': 1.9e-3, 'norm_lo': 0.9977, 'norm_hi': 1.0011, 'total_lo': 0.99994, 'total_hi': 1.00006}
+
+
+@pytest.mark.parametrize('S,B', [(32, 256), (64, 64)])
+def test_bench_batch_in_one_microbatch_equals_the_oracle_checked_dispatch(full, dev, S, B):
+    """Binds the BENCH configuration to the oracle-checked one.  bench.py runs the per-GPU batch (256 at 32^2, 64 at 64^2) as
+    ONE microbatch, where the dispatch differs from the B = 1-2 steps the oracle fixtures check (16-wave persistent GEMM
+    forms, register-resident GroupNorm, 128-way weight-gradient splits, 64-query attention tiles).  Property: the same batch
+    accumulated as microbatches of 2 - the dispatch `test_full_width_train_step_vs_oracle_fixture` checks against the oracle
+    - must give the same loss and the same gradient, tensor by tensor (north_star: "results match ... on identical
+    (latents, timesteps, text_embeds, noise)", reference stable_diffusion.py:183-187 under Composer's microbatching,
+    SD-2-base-256.yaml:87)."""
+    O, sd, model = full
+    g = torch.Generator().manual_seed(4200 + S)
+    lat = torch.randn(B, 4, S, S, generator=g)
+    ctx = torch.randn(B, 77, 1024, generator=g)
+    noise = torch.randn(B, 4, S, S, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    unet = model.unet
+
+    def step(mb):
+        unet.zero_grad()
+        total = 0.0
+        for s in range(0, B, mb):
+            sub = {'image_latents': lat[s:s + mb].to(dev), 'caption_latents': ctx[s:s + mb].to(dev)}
+            out = model(sub, timesteps=t[s:s + mb].to(dev), noise=noise[s:s + mb].to(dev))
+            w = mb / B
+            loss = model.loss(out, sub, weight=w)
+            model.backward_from_loss()
+            total += loss.item() * w
+        torch.cuda.synchronize()
+        norms = np.array([float(params[k].grad.detach().double().norm()) for k in keys])   # views of the flat gradient
+        return total, unet.grad.detach().clone(), norms
+
+    keys = [k for k, _ in O.param_manifest(O.UNetConfig.sd2_base())]
+    params = dict(unet.named_parameters())
+    loss_acc, g_acc, n_acc = step(2)          # the oracle-checked dispatch, accumulated
+    loss_one, g_one, n_one = step(B)          # the bench's dispatch
+    dl = abs(loss_one - loss_acc)
+    rel = ((g_one - g_acc).norm() / g_acc.norm()).item()
+    tot = (g_one.norm() / g_acc.norm()).item()
+    big = n_acc > 1e-3 * n_acc.max()
+    ratio = n_one[big] / n_acc[big]
+    worst = int(np.argmax(np.abs(ratio - 1.0)))
+    _record(f'bench_batch_s{S}_b{B}_vs_microbatch2', tol=TOL_BATCH, loss_one_microbatch=loss_one, loss_accumulated=loss_acc,
+            loss_abs_delta=dl, grad_rel_l2=rel, total_norm_ratio=tot, norm_ratio_min=float(ratio.min()),
+            norm_ratio_max=float(ratio.max()), worst_norm_tensor=str(np.array(keys)[big][worst]), tensors_compared=int(big.sum()))
+    assert dl < TOL_BATCH['loss_abs'], (loss_one, loss_acc)
+    assert rel < TOL_BATCH['grad_rel'], rel
+    assert TOL_BATCH['total_lo'] < tot < TOL_BATCH['total_hi'], tot
+    assert np.all((ratio > TOL_BATCH['norm_lo']) & (ratio < TOL_BATCH['norm_hi'])), (np.array(keys)[big][worst], ratio[worst])
