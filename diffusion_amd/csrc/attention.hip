@@ -630,9 +630,264 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward for SHORT key sequences (cross-attention: Nk = 77 text tokens <= 128), ONE kernel for dQ, dK and dV.
+// The two-kernel backward reads Q and dO twice (once per kernel) and O once for 77 keys' worth of arithmetic: 0.84 GB of
+// reads + 0.17 GB of dQ per level-0 layer at batch 256, 164 TFLOP/s.  Here the key-major sweep of attn_bwd_dkv_kernel
+// (all keys of an (image, head) live in ONE workgroup: wave w holds keys 32w..32w+31 and their dK^T / dV^T accumulators)
+// also produces dQ: every wave leaves its dS tile - bf16, [key][query] - in LDS before the tile's barrier, and after it
+// each wave multiplies ALL keys' dS by a 16-column slice of K (K^T fragments kept in registers for the whole sweep):
+// dQ^T[d slice][32 queries] = K^T . dS^T, three v_mfma_f32_16x16x32_bf16 per 16 queries, complete after one tile (no
+// accumulation over key blocks, no atomics: bitwise reproducible), stored as 8 bytes per lane.  delta = rowsum(dO * O)
+// is computed from the O tile (a third LDS image per stage) by the lanes that hold the dO row fragments anyway and
+// reaches the accumulator rows through a wave-private 128-byte LDS scratch.  Q, dO and O are read once.
+// 32-query tiles, three stages, requests two tiles ahead, one barrier per tile.
+// ------------------------------------------------------------------------------------------------
+constexpr int FU_STAGE = 3 * 32 * 128 + 256;     // Q, dO, O images + the 32 L2 values (one 4-byte LDS-DMA of wave 0: 64 lanes x 4 B)
+constexpr int FU_DS = 128 * 64;                  // dS^T image: [key 128][query 32] bf16, 64-byte rows
+constexpr int FU_SMEM = 3 * FU_STAGE + 2 * FU_DS + 4 * 128;
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const dsbuf = smem + 3 * FU_STAGE;         // two dS^T images (tile parity); first holds the K image during set-up
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const dscr = reinterpret_cast<float*>(smem + 3 * FU_STAGE + 2 * FU_DS + wave * 128);  // this wave's delta row
+  const int h = lane >> 5, r = lane & 31;
+  int blk, hd, b;
+  xcd_block_id(blk, hd, b);  // grid (1, H, B): blk == 0
+  const int key = wave * 32 + r;
+  const bool kv = key < p.Nk;
+  const int nkb = (p.Nk + 31) / 32;  // 32-key blocks that hold real keys (<= 4)
+
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = hd * 64 + ks * 16 + h * 8;
+    kf[ks] = kv ? ld8(p.K + ((long)b * p.Nk + key) * p.ldk + c) : zero8();
+    vf[ks] = kv ? ld8(p.V + ((long)b * p.Nk + key) * p.ldv + c) : zero8();
+  }
+  // ---- K^T fragments of this wave's 16-column slice (d = 16*wave .. +15) for the dQ product: the K rows go through a plain
+  // [key][64] image once (rows of keys past Nk are zero, so whatever their dS holds adds nothing), read transposed
+  {
+    const int krow = tid >> 1, half = tid & 1;  // 128 rows x two 64-byte halves
+    const bf16* src = p.K + ((long)b * p.Nk + krow) * p.ldk + hd * 64 + half * 32;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bf16x8 v = krow < p.Nk ? ld8(src + c * 8) : zero8();
+      *reinterpret_cast<bf16x8*>(dsbuf + krow * 128 + half * 64 + c * 16) = v;
+    }
+  }
+  __syncthreads();
+  // A operand of v_mfma_f32_16x16x32_bf16: lane l holds A[row l&15][k = 8*(l>>4) + j] = K[key kb+8*(l>>4)+j][d0 + (l&15)]:
+  // per 16-lane group two transposed 4-row x 16-column blocks (rows kb + 8g .. +3 and +4 .. +7, columns d0 .. d0+15)
+  bf16x8 ktf[4];
+  {
+    const int g = lane >> 4, i = lane & 15;
+    const unsigned base = lds_offset(dsbuf) + (unsigned)((8 * g + (i >> 2)) * 128 + (16 * wave + 4 * (i & 3)) * 2);
+    short4v t0[4], t1[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      t0[kb] = lds_tr16_b64_asm(base + kb * 32 * 128);
+      t1[kb] = lds_tr16_b64_asm(base + kb * 32 * 128 + 4 * 128);
+    }
+    lds_wait_for<0>(t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) ktf[kb] = tr_frag_join(t0[kb], t1[kb]);
+  }
+  __syncthreads();  // the K image is dead: its memory is the dS^T buffers from here on
+
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
+
+  const int nt = (p.Nq + 31) / 32;
+  const int drow = wave * 8 + (lane >> 3), pc = lane & 7;
+  const int lc = (pc ^ swz_key(drow)) * 8;
+  const bf16* qp = p.Q + ((long)b * p.Nq + drow) * p.ldq + hd * 64;
+  const bf16* dop = p.dO + ((long)b * p.Nq + drow) * p.lddo + hd * 64;
+  const bf16* op = p.O + ((long)b * p.Nq + drow) * p.ldo + hd * 64;
+  const long stat0 = ((long)b * p.H + hd) * p.Nq;
+  const float* statp = p.L2 + stat0 + (lane & 31);
+  const char* zero = reinterpret_cast<const char*>(g_attn_zero);
+  auto dma = [&](int t, int st) {  // tiles are requested in order
+    char* S = smem + st * FU_STAGE + wave * 1024;
+    const bool ok = t * 32 + drow < p.Nq;
+    dma16(ok ? (const void*)(qp + lc) : (const void*)zero, S);
+    dma16(ok ? (const void*)(dop + lc) : (const void*)zero, S + 4096);
+    dma16(ok ? (const void*)(op + lc) : (const void*)zero, S + 8192);
+    if (wave == 0) {
+      const bool ok2 = t * 32 + (lane & 31) < p.Nq;
+      dma4(ok2 ? (const void*)statp : (const void*)zero, smem + st * FU_STAGE + 3 * 4096);
+    }
+    qp += 32 * p.ldq;
+    dop += 32 * p.lddo;
+    op += 32 * p.ldo;
+    statp += 32;
+  };
+  auto sync_tiles = [&](bool newest_in_flight) {
+    if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (wave == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // dQ rows of tile t from the dS^T image the tile left behind (all waves' keys), this wave's 16 columns
+  auto dq_tile = [&](int t) {
+    const int g = lane >> 4, i = lane & 15;
+    const unsigned base = lds_offset(dsbuf + (t & 1) * FU_DS) + (unsigned)((8 * g + (i >> 2)) * 64 + (4 * (i & 3)) * 2);
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    short4v t0[2][4], t1[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        t0[qt][kb] = lds_tr16_b64_asm(base + kb * 32 * 64 + qt * 32);
+        t1[qt][kb] = lds_tr16_b64_asm(base + kb * 32 * 64 + qt * 32 + 4 * 64);
+      }
+    lds_wait_for<0>(t0[0][0], t0[0][1], t0[0][2], t0[0][3], t1[0][0], t1[0][1], t1[0][2], t1[0][3], t0[1][0], t0[1][1], t0[1][2],
+                    t0[1][3], t1[1][0], t1[1][1], t1[1][2], t1[1][3]);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+        if (kb < nkb) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[kb], tr_frag_join(t0[qt][kb], t1[qt][kb]), acc[qt], 0, 0, 0);
+    // D[d = 4*(l>>4) + e][q = l&15]: four consecutive columns of one dQ row per lane
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = t * 32 + qt * 16 + i;
+      if (q < p.Nq) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[qt][e] * p.scale);
+        *reinterpret_cast<bf16x4*>(p.dQ + ((long)b * p.Nq + q) * p.lddq + hd * 64 + 16 * wave + 4 * g) = o;
+      }
+    }
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K / V fragments above: keep the counted waits below exact
+  dma(0, 0);
+  if (nt > 1) dma(1, 1);
+  sync_tiles(nt > 1);
+  float delta_prev = 0.f;
+  for (int t = 0; t < nt; ++t) {
+    // the stores of tile t-1 (dQ rows, delta) go out BEFORE the requests of tile t+2: the step-end wait leaves exactly the
+    // newest tile's requests in flight (vmcnt counts stores too, in order), so anything issued after them would have to be
+    // counted as well - and a store whose lanes are all masked off might not be issued at all
+    if (t > 0) {
+      dq_tile(t - 1);  // (its dS^T image was completed by the barrier that ended step t-1)
+      if (wave == 0 && h == 0 && (t - 1) * 32 + r < p.Nq) p.Delta[stat0 + (t - 1) * 32 + r] = delta_prev;
+    }
+    if (t + 2 < nt) dma(t + 2, (t + 2) % 3);
+    const char* Qs = smem + (t % 3) * FU_STAGE;
+    const char* Os = Qs + 4096;
+    const char* Oo = Qs + 8192;
+    const float* Ls = reinterpret_cast<const float*>(Qs + 3 * 4096);
+    // dO and O row fragments of query r: this lane's 32 of the row's 64 columns -> half of delta[r]; the other half is in lane ^ 32
+    bf16x8 of[4];
+    float dpart = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      of[ks] = *reinterpret_cast<const bf16x8*>(Os + swz128(r, 2 * ks + h));
+      const bf16x8 oo = *reinterpret_cast<const bf16x8*>(Oo + swz128(r, 2 * ks + h));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dpart = fmaf(bf2f(of[ks][j]), bf2f(oo[j]), dpart);
+    }
+    const float delta = dpart + xor32(dpart);
+    if (h == 0) dscr[r] = delta;
+    delta_prev = delta;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (same wave: the scratch row is written before it is read back)
+    f32x16 s, dp;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(dscr + 8 * rg + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[4 * rg + e] = 0.f; dp[4 * rg + e] = -d4[e]; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + swz128(r, 2 * ks + h));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);       // S[q][key]
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ks], vf[ks], dp, 0, 0, 0);  // dP[q][key] - delta[q]
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    short4v to0[2][2], to1[2][2], tq0[2][2], tq1[2][2];
+    const unsigned oto = lds_offset(Os), qto = lds_offset(Qs);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      tr_frag_issue(oto, 16 * s2, 0, lane, to0[s2][0], to0[s2][1]);
+      tr_frag_issue(oto, 16 * s2, 32, lane, to1[s2][0], to1[s2][1]);
+      tr_frag_issue(qto, 16 * s2, 0, lane, tq0[s2][0], tq0[s2][1]);
+      tr_frag_issue(qto, 16 * s2, 32, lane, tq1[s2][0], tq1[s2][1]);
+    }
+    f32x16 pr;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + 8 * rg + 4 * h);
+      const f32x2 sc2 = {p.sc, p.sc};
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int i = rg * 2 + e2;
+        const f32x2 pv = exp2_2(__builtin_elementwise_fma(pair(s, i), sc2, -f32x2{l4[2 * e2], l4[2 * e2 + 1]}));
+        set_pair(pr, i, pv);
+        set_pair(s, i, pv * pair(dp, i));
+      }
+    }
+    bf16x8 pf[2] = {pack8(pr, 0), pack8(pr, 1)};
+    bf16x8 dsf[2] = {pack8(s, 0), pack8(s, 1)};
+    // dS^T -> LDS for the dQ product after the barrier: registers 4*rg .. 4*rg+3 are queries 8*rg + 4*h .. +3 of this lane's key
+    {
+      char* drow_p = dsbuf + (t & 1) * FU_DS + key * 64 + 8 * h;
+      typedef __attribute__((ext_vector_type(4))) short short4w;
+      typedef __attribute__((ext_vector_type(8))) short short8w;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const short8w v = __builtin_bit_cast(short8w, dsf[s2]);
+        *reinterpret_cast<short4w*>(drow_p + 32 * s2) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+        *reinterpret_cast<short4w*>(drow_p + 32 * s2 + 16) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+      }
+    }
+    lds_wait_for<0>(to0[0][0], to0[0][1], to1[0][0], to1[0][1], tq0[0][0], tq0[0][1], tq1[0][0], tq1[0][1], to0[1][0],
+                    to0[1][1], to1[1][0], to1[1][1], tq0[1][0], tq0[1][1], tq1[1][0], tq1[1][1]);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(to0[s2][0], to0[s2][1]), pf[s2], dv0, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(to1[s2][0], to1[s2][1]), pf[s2], dv1, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tq0[s2][0], tq0[s2][1]), dsf[s2], dk0, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_join(tq1[s2][0], tq1[s2][1]), dsf[s2], dk1, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the dS^T rows are in LDS before the barrier
+    sync_tiles(t + 2 < nt);
+  }
+  dq_tile(nt - 1);
+  if (wave == 0 && h == 0 && (nt - 1) * 32 + r < p.Nq) p.Delta[stat0 + (nt - 1) * 32 + r] = delta_prev;
+  if (kv) {
+    bf16* kp = p.dK + ((long)b * p.Nk + key) * p.lddk + hd * 64;
+    bf16* vp = p.dV + ((long)b * p.Nk + key) * p.lddv + hd * 64;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      bf16x4 a, c, e0, e1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = f2bf(dk0[rg * 4 + e] * p.scale);
+        c[e] = f2bf(dk1[rg * 4 + e] * p.scale);
+        e0[e] = f2bf(dv0[rg * 4 + e]);
+        e1[e] = f2bf(dv1[rg * 4 + e]);
+      }
+      *reinterpret_cast<bf16x4*>(kp + 8 * rg + 4 * h) = a;
+      *reinterpret_cast<bf16x4*>(kp + 32 + 8 * rg + 4 * h) = c;
+      *reinterpret_cast<bf16x4*>(vp + 8 * rg + 4 * h) = e0;
+      *reinterpret_cast<bf16x4*>(vp + 32 + 8 * rg + 4 * h) = e1;
+    }
+  }
+}
+
 int check(long ld) { return (ld & 7) ? 1 : 0; }
 
 }  // namespace
+
+int g_attn_fused_bwd = 1;  // da_set_option("attn_fused_bwd", 0 | 1): the one-kernel backward for Nk <= 128 (cross-attention)
 
 #ifdef DA_STAMPS
 extern "C" int da_debug_set_attn_stamps(void* buf, int wgs) {
@@ -687,6 +942,13 @@ extern "C" int da_attn_bwd(const void* Q, long ldq, const void* K, long ldk, con
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
   p.scale = scale; p.sc = scale * 1.4426950408889634f;
+  if (g_attn_fused_bwd && Nk <= 128 && Nq >= 64) {  // all keys of an (image, head) fit one workgroup: one kernel for dQ, dK, dV
+    static unsigned long long attr_done = 0;
+    if (da_ensure_dyn_smem((const void*)attn_bwd_fused_kernel, FU_SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
+    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(1, H, B), dim3(256), FU_SMEM, stream, p);
+    DA_CHECK_LAUNCH();
+    return DA_OK;
+  }
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 2 * DQ_STAGE, stream, p);
   DA_CHECK_LAUNCH();
   if (Nq >= 128)
