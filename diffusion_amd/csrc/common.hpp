@@ -44,6 +44,11 @@ DEVINL bf16 f2bf(float x) { return (bf16)x; }
 
 DEVINL bf16x8 ld8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 DEVINL void st8(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+// 16-byte store with the non-temporal hint (global_store_dwordx4 ... nt): output rows a kernel writes once and never reads
+DEVINL void st8_nt(bf16* p, bf16x8 v) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
+  __builtin_nontemporal_store(__builtin_bit_cast(u32x4s, v), reinterpret_cast<u32x4s*>(p));
+}
 DEVINL bf16x8 zero8() {
   bf16x8 z;
 #pragma unroll

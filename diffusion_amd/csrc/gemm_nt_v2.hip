@@ -15,6 +15,21 @@
 // Epilogue variants: plain (bias / per-image row bias / residual), GEGLU forward, GEGLU backward, split-K slabs.
 #include "common.hpp"
 #include "diffusion_amd.h"
+// NT2_NT=1 (compile-time experiment, round 4; default 0): the output rows of the short-K forms leave with the NON-TEMPORAL
+// hint (global_store_dwordx4 ... nt).  In isolation (tools/lib_ab.py, the same launch repeated; profiles/r04_ab_nt_ntstore.txt)
+// 262144 x 960 x 320 ran +20.8 %, x 320 x 320 +4...8 %, the fused GEGLU forward +5...12 % (3 x 3 convolutions -1...-3 %, GEGLU
+// backward -3 %) - and the whole training step did not move (169.4 / 168.6 vs 169.1 / 169.1 ms, two interleaved pairs on one
+// box): inside the step the consumer of those rows is the next launch, which finds a good part of a plainly stored 168 MB
+// tensor in the 256 MB Infinity Cache and none of a non-temporal one.  Per-launch A/B numbers of byte-bound kernels do not
+// carry over to the step; only whole-step A/Bs (DA_LIB_ALT / DA_SET_OPTIONS) decide.
+#ifndef NT2_NT
+#define NT2_NT 0
+#endif
+#if NT2_NT
+#define NTST st8_nt
+#else
+#define NTST st8
+#endif
 
 
 // NT2_CT (convolution forms, i.e. !EARLY): the 16x16x32 products are taken TRANSPOSED (W fragment as the first MFMA operand),
@@ -663,9 +678,9 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
             }
           }
           bf16* fp = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + h0 + c8;
-          st8(fp, fv);
-          st8(fp + p.inner, fg);
-          st8(p.G + (long)m * p.ldg + h0 + c8, og);
+          NTST(fp, fv);
+          NTST(fp + p.inner, fg);
+          NTST(p.G + (long)m * p.ldg + h0 + c8, og);
         }
       }
       lds_barrier();  // single strip buffer: everyone is done reading before it is rewritten
@@ -844,7 +859,8 @@ DEVINL void nt2_tile(const GemmNT2Params& p, const int vblock0, char* smem) {
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-          st8(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, o);
+          if constexpr (EARLY) NTST(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, o);
+          else st8(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, o);
         }
       }
     }
@@ -990,14 +1006,13 @@ int launch_v2_mode(const GemmNT2Params& p0, int splits, float* ws, hipStream_t s
     DA_CHECK_LAUNCH();
     return DA_OK;
   }
-  if constexpr (MF == 16 && !EARLY && ((NT % 2) == 0 || (MT % 2) == 0)) {
-    // direct epilogue (see nt2_tile, DE) - convolution forms only: on the short-K linears it measured -2...+2 % without a
-    // residual and -7...-13 % with one (its 16-row x 64-byte residual reads against the strip path's whole 640-byte rows;
-    // profiles/r04_ab_nt_de.txt), because there the tile is paced by the DRAIN of its stores, not by the epilogue's
-    // instructions (a timing-only build without the stores ran 95 -> 56 us at 262144 x 320 x 320)
-    // direct epilogue (see nt2_tile, DE): bf16 output, alpha 1 (bias already in the accumulators), 16-byte aligned rows,
-    // everything inside 32-bit byte offsets
-    const bool de = g_nt_de && !p.out_fp32 && p.alpha == 1.0f && (p.N % 8) == 0 && (p.ldc % 8) == 0 && !((uintptr_t)p.C & 15) &&
+  if constexpr (MF == 16 && ((NT % 2) == 0 || (MT % 2) == 0)) {
+    // direct epilogue (see nt2_tile, DE).  Default (gemm_nt_de = 1): the convolution forms only - on the short-K linears it
+    // measured -2...+2 % without a residual and -7...-13 % with one in isolation (its 16-row x 64-byte residual reads against
+    // the strip path's whole 640-byte rows; profiles/r04_ab_nt_de.txt).  gemm_nt_de = 2 adds the linears without a residual,
+    // 3 those with one (whole-step A/B switches).
+    const bool form_ok = !EARLY || g_nt_de >= 3 || (g_nt_de == 2 && !p.R);
+    const bool de = g_nt_de && form_ok && !p.out_fp32 && p.alpha == 1.0f && (p.N % 8) == 0 && (p.ldc % 8) == 0 && !((uintptr_t)p.C & 15) &&
                     (long)p.M * p.ldc * 2 < (1L << 32) &&
                     (!p.R || ((p.ldr % 8) == 0 && !((uintptr_t)p.R & 15) && (long)p.M * p.ldr * 2 < (1L << 32))) &&
                     (!p.rowbias || ((p.ldrb % 4) == 0 && !((uintptr_t)p.rowbias & 7)));

@@ -13,7 +13,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # which kind of box is this?  (the pool's MI355X differ by several per cent; PROBE_STRICT=1 stops on a slow one)
@@ -22,7 +22,12 @@ cat $O/box_probe.txt
 BENCH_SHAPES=1 python3 $R/bench.py > $O/bench_256.json 2> $O/per_shape_in_situ.txt || exit 1
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $ROUND -- python3 $R/bench.py --no-cpu-baseline --no-secondary > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
+python3 $R/tools/trace_step_table.py $(ls $O/stats/*/*kernel_trace.csv $O/stats/*kernel_trace.csv 2>/dev/null | head -1) > $O/bench_kernel_steps.txt || exit 1
 echo "stats done"
+# the 512-px half of the metric (latents 4x64x64, batch 64): the same trace + per-step table
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats512 -o $ROUND -- python3 $R/bench.py --latent 64 --no-cpu-baseline --no-secondary > $O/bench_512_under_rocprof.json 2> $O/stats512.err || exit 1
+python3 $R/tools/trace_step_table.py $(ls $O/stats512/*/*kernel_trace.csv $O/stats512/*kernel_trace.csv 2>/dev/null | head -1) > $O/bench_kernel_steps_512.txt || exit 1
+echo "stats 512 done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timing --no-secondary --steps 1 --warmup 1 > /dev/null 2> $O/pmc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timing --no-secondary --steps 1 --warmup 1 > /dev/null 2> $O/pmc_write.err || exit 1
 echo "pmc done"

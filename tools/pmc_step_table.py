@@ -18,7 +18,8 @@ def short(n):
     name, t = m.group(1), (m.group(2) or '').replace(' ', '')
     if name == 'gemm_nt2_kernel':
         a = t.strip('<>').split(',')
-        return 'nt2<%s|ups%s|geglu%s|early%s|persist%s>' % (','.join(a[:4]), a[5][0], a[6], a[7][0], a[9][0] if len(a) > 9 else '?')
+        return 'nt2<%s|ups%s|geglu%s|early%s|persist%s|de%s%s>' % (','.join(a[:4]), a[5][0], a[6], a[7][0], a[9][0] if len(a) > 9 else '?',
+                                                             a[10][0] if len(a) > 10 else 'f', a[11][0] if len(a) > 11 else 'f')
     return name + t[:24]
 
 
