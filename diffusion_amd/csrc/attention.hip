@@ -644,10 +644,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
 // 32-query tiles, three stages, requests two tiles ahead, one barrier per tile.
 // ------------------------------------------------------------------------------------------------
 constexpr int FU_STAGE = 3 * 32 * 128 + 256;     // Q, dO, O images + the 32 L2 values (one 4-byte LDS-DMA of wave 0: 64 lanes x 4 B)
-constexpr int FU_DS = 128 * 64;                  // dS^T image: [key 128][query 32] bf16, 64-byte rows
-constexpr int FU_SMEM = 3 * FU_STAGE + 2 * FU_DS + 4 * 128;
+constexpr int fu_ds(int NW) { return 32 * NW * 64; }   // dS^T image: [key 32*NW][query 32] bf16, 64-byte rows
+constexpr int fu_smem(int NW) { return 3 * FU_STAGE + 2 * fu_ds(NW) + NW * 128; }
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnParams p) {
+// NW = 4: up to 128 keys, two workgroups per CU (cross-attention, the 64-token level); NW = 8: up to 256 keys, one
+// 8-wave workgroup per CU (the 256-token level): waves 0-3 request the tiles, every wave holds 32 keys, the dQ product is
+// dealt as (16-column slice = wave & 3) x (16-query half = wave >> 2).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(AttnParams p) {
+  constexpr int FU_DS = fu_ds(NW);
+  constexpr int QTW = 8 / NW;  // 16-query tiles of the dQ product per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const dsbuf = smem + 3 * FU_STAGE;         // two dS^T images (tile parity); first holds the K image during set-up
   const int tid = threadIdx.x, lane = tid & 63;
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnParams p) {
   xcd_block_id(blk, hd, b);  // grid (1, H, B): blk == 0
   const int key = wave * 32 + r;
   const bool kv = key < p.Nk;
-  const int nkb = (p.Nk + 31) / 32;  // 32-key blocks that hold real keys (<= 4)
+  const int nkb = (p.Nk + 31) / 32;  // 32-key blocks that hold real keys (<= NW)
 
   bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -670,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnParams p) {
   // ---- K^T fragments of this wave's 16-column slice (d = 16*wave .. +15) for the dQ product: the K rows go through a plain
   // [key][64] image once (rows of keys past Nk are zero, so whatever their dS holds adds nothing), read transposed
   {
-    const int krow = tid >> 1, half = tid & 1;  // 128 rows x two 64-byte halves
+    const int krow = tid >> 1, half = tid & 1;  // 32*NW rows x two 64-byte halves
     const bf16* src = p.K + ((long)b * p.Nk + krow) * p.ldk + hd * 64 + half * 32;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -681,19 +687,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnParams p) {
   __syncthreads();
   // A operand of v_mfma_f32_16x16x32_bf16: lane l holds A[row l&15][k = 8*(l>>4) + j] = K[key kb+8*(l>>4)+j][d0 + (l&15)]:
   // per 16-lane group two transposed 4-row x 16-column blocks (rows kb + 8g .. +3 and +4 .. +7, columns d0 .. d0+15)
-  bf16x8 ktf[4];
+  bf16x8 ktf[NW];
+  const int dsl = wave & 3;  // this wave's 16-column slice of dQ
   {
     const int g = lane >> 4, i = lane & 15;
-    const unsigned base = lds_offset(dsbuf) + (unsigned)((8 * g + (i >> 2)) * 128 + (16 * wave + 4 * (i & 3)) * 2);
-    short4v t0[4], t1[4];
+    const unsigned base = lds_offset(dsbuf) + (unsigned)((8 * g + (i >> 2)) * 128 + (16 * dsl + 4 * (i & 3)) * 2);
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      t0[kb] = lds_tr16_b64_asm(base + kb * 32 * 128);
-      t1[kb] = lds_tr16_b64_asm(base + kb * 32 * 128 + 4 * 128);
+    for (int kb = 0; kb < NW; ++kb) {
+      short4v t0 = lds_tr16_b64_asm(base + kb * 32 * 128);
+      short4v t1 = lds_tr16_b64_asm(base + kb * 32 * 128 + 4 * 128);
+      lds_wait_for<0>(t0, t1);
+      ktf[kb] = tr_frag_join(t0, t1);
     }
-    lds_wait_for<0>(t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]);
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) ktf[kb] = tr_frag_join(t0[kb], t1[kb]);
   }
   __syncthreads();  // the K image is dead: its memory is the dS^T buffers from here on
 
@@ -702,7 +707,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnParams p) {
   for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
 
   const int nt = (p.Nq + 31) / 32;
-  const int drow = wave * 8 + (lane >> 3), pc = lane & 7;
+  const bool loader = wave < 4;  // waves 0-3 fill rows 8w .. 8w+7 of the three images
+  const int drow = (wave & 3) * 8 + (lane >> 3), pc = lane & 7;
   const int lc = (pc ^ swz_key(drow)) * 8;
   const bf16* qp = p.Q + ((long)b * p.Nq + drow) * p.ldq + hd * 64;
   const bf16* dop = p.dO + ((long)b * p.Nq + drow) * p.lddo + hd * 64;
@@ -711,6 +717,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnParams p) {
   const float* statp = p.L2 + stat0 + (lane & 31);
   const char* zero = reinterpret_cast<const char*>(g_attn_zero);
   auto dma = [&](int t, int st) {  // tiles are requested in order
+    if (!loader) return;
     char* S = smem + st * FU_STAGE + wave * 1024;
     const bool ok = t * 32 + drow < p.Nq;
     dma16(ok ? (const void*)(qp + lc) : (const void*)zero, S);
@@ -726,9 +733,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnParams p) {
     statp += 32;
   };
   auto sync_tiles = [&](bool newest_in_flight) {
-    if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (wave == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (loader) {  // (the other waves have no tile requests of their own to wait for)
+      if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (wave == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -737,31 +746,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnParams p) {
     const int g = lane >> 4, i = lane & 15;
     const unsigned base = lds_offset(dsbuf + (t & 1) * FU_DS) + (unsigned)((8 * g + (i >> 2)) * 64 + (4 * (i & 3)) * 2);
     typedef float f32x4v __attribute__((ext_vector_type(4)));
-    f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    short4v t0[2][4], t1[2][4];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qi = 0; qi < QTW; ++qi) {
+      const int qt = (wave >> 2) * QTW + qi;  // 16-query tile of the 32-query step
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+      short4v t0[NW], t1[NW];
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        t0[qt][kb] = lds_tr16_b64_asm(base + kb * 32 * 64 + qt * 32);
-        t1[qt][kb] = lds_tr16_b64_asm(base + kb * 32 * 64 + qt * 32 + 4 * 64);
+      for (int kb = 0; kb < NW; ++kb) {
+        t0[kb] = lds_tr16_b64_asm(base + kb * 32 * 64 + qt * 32);
+        t1[kb] = lds_tr16_b64_asm(base + kb * 32 * 64 + qt * 32 + 4 * 64);
       }
-    lds_wait_for<0>(t0[0][0], t0[0][1], t0[0][2], t0[0][3], t1[0][0], t1[0][1], t1[0][2], t1[0][3], t0[1][0], t0[1][1], t0[1][2],
-                    t0[1][3], t1[1][0], t1[1][1], t1[1][2], t1[1][3]);
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-        if (kb < nkb) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[kb], tr_frag_join(t0[qt][kb], t1[qt][kb]), acc[qt], 0, 0, 0);
-    // D[d = 4*(l>>4) + e][q = l&15]: four consecutive columns of one dQ row per lane
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+      for (int kb = 0; kb < NW; ++kb) {
+        lds_wait_for<0>(t0[kb], t1[kb]);
+        if (kb < nkb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[kb], tr_frag_join(t0[kb], t1[kb]), acc, 0, 0, 0);
+      }
+      // D[d = 4*(l>>4) + e][q = l&15]: four consecutive columns of one dQ row per lane
       const int q = t * 32 + qt * 16 + i;
       if (q < p.Nq) {
         bf16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[qt][e] * p.scale);
-        *reinterpret_cast<bf16x4*>(p.dQ + ((long)b * p.Nq + q) * p.lddq + hd * 64 + 16 * wave + 4 * g) = o;
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[e] * p.scale);
+        *reinterpret_cast<bf16x4*>(p.dQ + ((long)b * p.Nq + q) * p.lddq + hd * 64 + 16 * dsl + 4 * g) = o;
       }
     }
   };
@@ -944,8 +950,15 @@ extern "C" int da_attn_bwd(const void* Q, long ldq, const void* K, long ldk, con
   p.scale = scale; p.sc = scale * 1.4426950408889634f;
   if (g_attn_fused_bwd && Nk <= 128 && Nq >= 64) {  // all keys of an (image, head) fit one workgroup: one kernel for dQ, dK, dV
     static unsigned long long attr_done = 0;
-    if (da_ensure_dyn_smem((const void*)attn_bwd_fused_kernel, FU_SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
-    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(1, H, B), dim3(256), FU_SMEM, stream, p);
+    if (da_ensure_dyn_smem((const void*)attn_bwd_fused_kernel<4>, fu_smem(4), &attr_done) != DA_OK) return DA_ERR_LAUNCH;
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<4>, dim3(1, H, B), dim3(256), fu_smem(4), stream, p);
+    DA_CHECK_LAUNCH();
+    return DA_OK;
+  }
+  if (g_attn_fused_bwd >= 2 && Nk <= 256 && Nq >= 64) {  // ... as one 8-wave workgroup (da_set_option("attn_fused_bwd", 2))
+    static unsigned long long attr_done8 = 0;
+    if (da_ensure_dyn_smem((const void*)attn_bwd_fused_kernel<8>, fu_smem(8), &attr_done8) != DA_OK) return DA_ERR_LAUNCH;
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, dim3(1, H, B), dim3(512), fu_smem(8), stream, p);
     DA_CHECK_LAUNCH();
     return DA_OK;
   }
