@@ -87,6 +87,7 @@ def test_kernel_spill_budget():
         'gemm_nt2_kernelILi4ELi5ELi4ELi4ELi64ELb0ELi0ELb0ELi16ELb1ELb1ELb1E': 5,   # ... with the direct epilogue + residual (none in the K loop)
         'gemm_nt2_kernelILi4ELi5ELi4ELi4ELi64ELb0ELi0ELb1ELi16ELb1ELb1ELb1E': 13,  # linear form, direct epilogue + residual: opt-in only (gemm_nt_de = 3)
         'gemm_nt2_kernelILi4ELi5ELi4ELi4ELi64ELb0ELi2ELb1ELi16ELb1E': 2,     # fused GEGLU backward
+        'attn_bwd_fused_kernelILi8E': 1,     # 8-wave form of the one-kernel attention backward: opt-in only (attn_fused_bwd = 2)
         'gn_res_bwd_kernelILi11ELb1ELi1024E': 2, 'gn_res_bwd_kernelILi11ELb0ELi1024E': 2}
     seen = 0
     for f in reports:
