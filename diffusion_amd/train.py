@@ -37,6 +37,14 @@ def train(config) -> None:
         _recursive_=False,
     )
 
+    # evaluation data (reference train.py:44-63): a plain `dataset.eval_dataset` is built like the train loader with the
+    # per-rank share of `eval_batch_size`; `dataset.evaluators` (FID / CLIP-score Evaluator objects) are out of scope
+    eval_dataloader = None
+    ds = config.dataset
+    if 'eval_dataset' in ds and ds.eval_dataset and '_target_' in ds.eval_dataset:
+        eval_dataloader = hydra.instantiate(ds.eval_dataset, batch_size=int(ds.get('eval_batch_size', ds.train_batch_size)) // world,
+                                            _recursive_=False)
+
     callbacks = []
     if 'callbacks' in config and config.callbacks:
         for _, call_conf in config.callbacks.items():
@@ -55,7 +63,7 @@ def train(config) -> None:
     trainer = hydra.instantiate(
         trainer_conf,
         train_dataloader=train_dataloader,
-        eval_dataloader=None,
+        eval_dataloader=eval_dataloader,
         optimizers=optimizer,
         model=model,
         loggers=[],
@@ -64,7 +72,7 @@ def train(config) -> None:
         callbacks=callbacks,
     )
     if config.get('eval_first', True):
-        trainer.eval()
+        trainer.eval(subset_num_batches=trainer_conf.get('eval_subset_num_batches'))
     trainer.fit()
     if dist.is_initialized():
         dist.barrier()

@@ -90,7 +90,7 @@ class Trainer:
                  algorithms=None, eval_dataloader=None, eval_interval=None, device='gpu', run_name=None, seed=None,
                  scale_schedule_ratio: float = 1.0, save_folder=None, save_interval=None, save_overwrite=True,
                  autoresume=False, load_path=None, fsdp_config=None, precision=None, log_every: int = 10,
-                 use_graphs=False, **unused):
+                 use_graphs=False, eval_subset_num_batches=None, **unused):
         self.model = model
         self.dataloader = train_dataloader
         self.optimizer: FusedAdamW = optimizers
@@ -103,6 +103,9 @@ class Trainer:
         self.scheduler = schedulers
         self.callbacks: List[Callback] = [c for c in (callbacks or []) if isinstance(c, Callback)]
         self.algorithms = [a for a in (algorithms or []) if hasattr(a, 'before_optimizer_step')]
+        self.eval_dataloader = eval_dataloader
+        self.eval_interval = _parse_time(eval_interval)[0] if eval_interval else None
+        self.eval_subset_num_batches = eval_subset_num_batches
         self.save_folder = save_folder
         self.save_interval = _parse_time(save_interval)[0] if save_interval else None
         self.batch_idx = 0
@@ -298,13 +301,46 @@ class Trainer:
                 self.log({'loss/train/total': float(loss.item())})
             for c in self.callbacks:
                 c.batch_end(self)
+            if self.eval_interval and self.batch_idx % self.eval_interval == 0:
+                self.eval()
             if self.save_folder and self.save_interval and self.batch_idx % self.save_interval == 0:
                 self.save_checkpoint(os.path.join(self.save_folder, f'ba{self.batch_idx}-rank{self.rank}.pt'))
         for c in self.callbacks:
             c.fit_end(self)
 
-    def eval(self, subset_num_batches=None):  # evaluation (FID / sampling) is outside the hot path
-        return {}
+    @torch.no_grad()
+    def eval(self, subset_num_batches=None):
+        """``composer.Trainer.eval`` for the slice the reference drives (diffusion/train.py:118-136, `eval_first`, the trainer
+        block's `eval_interval` / `eval_subset_num_batches`): every batch of ``eval_dataloader`` goes through
+        ``model.eval_forward`` and every validation metric through ``model.update_metric`` (stable_diffusion.py:189-257); the
+        metric states are summed over the ranks (squared-error sum and count, as torchmetrics' dist_reduce_fx="sum" does) and
+        logged as ``metrics/eval/<name>``.  Image-generation metrics (FID / CLIP score: val_guidance_scales) need the
+        evaluation datasets and Inception / CLIP weights that are out of scope; with no eval dataloader this returns {}."""
+        if self.eval_dataloader is None:
+            return {}
+        model = self.model
+        metrics = model.get_metrics(is_train=False)
+        for m in metrics.values():
+            m.reset()
+        n = subset_num_batches if subset_num_batches is not None else self.eval_subset_num_batches
+        dev = model.unet.device_
+        for i, batch in enumerate(self.eval_dataloader):
+            if n is not None and n >= 0 and i >= n:
+                break
+            batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            outputs = model.eval_forward(batch)
+            for m in metrics.values():
+                model.update_metric(batch, outputs, m)
+        out = {}
+        for name, m in metrics.items():
+            if self.world > 1 and getattr(m, 'sum_squared_error', None) is not None:
+                st = torch.stack([m.sum_squared_error.double(), torch.tensor(float(m.total), device=dev, dtype=torch.float64)])
+                dist.all_reduce(st)
+                out[f'metrics/eval/{name}'] = float((st[0] / st[1]).item())
+            else:
+                out[f'metrics/eval/{name}'] = float(m.compute())
+        self.log(out)
+        return out
 
     # checkpoints keep the reference layout state['state']['model'] with diffusers key names under 'unet.' (what
     # diffusion/inference/inference_model.py:35-39 reads); optimizer moments, the EMA shadow and every algorithm's state

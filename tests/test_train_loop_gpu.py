@@ -229,3 +229,52 @@ def test_graph_replayed_microbatches_equal_eager(dev):
     # the metric the trainer updates reads the replayed outputs
     m = graphed.model.get_metrics(is_train=True)['MeanSquaredError']
     assert torch.isfinite(m.compute())
+
+
+def test_trainer_eval_drives_eval_forward_and_the_validation_metrics(dev):
+    """`composer.Trainer.eval` as the reference drives it (diffusion/train.py:118-136 `eval_first`, the trainer block's
+    `eval_interval` / `eval_subset_num_batches`): every batch of the eval dataloader through `model.eval_forward`, every
+    validation metric through `model.update_metric` (stable_diffusion.py:189-257, incl. the loss-bin masking), results
+    logged as metrics/eval/<name>.  Expected values are recomputed from `model(batch)` on the same injected t / noise."""
+    from diffusion_amd.models.models import stable_diffusion_2
+    from diffusion_amd.optim import FusedAdamW
+    from diffusion_amd.trainer import Trainer
+    model = stable_diffusion_2(model_name='tiny', pretrained=False, precomputed_latents=True, fsdp=False, seed=3,
+                               loss_bins=[(0.0, 0.5), (0.5, 1.0)])
+    opt = FusedAdamW(lr=1e-3, weight_decay=0.01, unet=model.unet)
+    g = torch.Generator().manual_seed(9)
+
+    def mk(n):
+        return {'image_latents': torch.randn(n, 4, 16, 16, generator=g).half(), 'caption_latents': torch.randn(n, 77, 128, generator=g).half(),
+                '_noise': torch.randn(n, 4, 16, 16, generator=g), '_timesteps': torch.randint(0, 1000, (n,), generator=g)}
+    evalset = [mk(4), mk(4), mk(2)]
+    trainset = [mk(4), mk(4)]
+    tr = Trainer(model, train_dataloader=trainset, optimizers=opt, max_duration='2ba', eval_dataloader=evalset,
+                 eval_interval='1ba', eval_subset_num_batches=2, log_every=1000)
+    # expected: squared error summed over the first two eval batches / element count, and the two timestep bins
+    with torch.no_grad():
+        se = cnt = 0.0
+        bins = {(0.0, 0.5): [0.0, 0.0], (0.5, 1.0): [0.0, 0.0]}
+        for b in evalset[:2]:
+            bd = {k: v.to(dev) for k, v in b.items()}
+            pred, target, t = model(bd)
+            model._pending = None
+            d2 = (pred.float() - target.float())**2
+            se += d2.sum().item(); cnt += d2.numel()
+            for (lo, hi), acc in bins.items():
+                sel = (t >= lo * 1000) & (t < hi * 1000)
+                acc[0] += d2[sel].sum().item(); acc[1] += d2[sel].numel()
+    out = tr.eval()
+    assert abs(out['metrics/eval/MeanSquaredError'] - se / cnt) < 1e-5 * max(1.0, se / cnt), (out, se / cnt)
+    for (lo, hi), acc in bins.items():
+        key = [k for k in out if f'bin-{lo}-to-{hi}'.replace('.', 'p') in k]
+        assert len(key) == 1, out.keys()
+        if acc[1]:
+            assert abs(out[key[0]] - acc[0] / acc[1]) < 1e-5 * max(1.0, acc[0] / acc[1])
+    assert tr.eval(subset_num_batches=3)['metrics/eval/MeanSquaredError'] != out['metrics/eval/MeanSquaredError']   # third batch counted
+    # eval_interval: one evaluation after each of the two training batches
+    before = sum('metrics/eval/MeanSquaredError' in d for d in tr.logs)
+    tr.fit()
+    assert sum('metrics/eval/MeanSquaredError' in d for d in tr.logs) == before + 2
+    # no eval dataloader: nothing to do (the reference's evaluators - FID, CLIP score - are out of scope)
+    assert Trainer(model, train_dataloader=None, optimizers=opt, max_duration='1ba').eval() == {}
