@@ -16,6 +16,7 @@ Architecture: SURVEY.md Appendix A.  This file is host orchestration only:
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -256,6 +257,9 @@ class UNetOutput(dict):
     @property
     def sample(self):
         return self['sample']
+
+
+_DGRAD_FIRST = os.environ.get('DA_DGRAD_FIRST', '0') == '1'
 
 
 class UNetHIP(nn.Module):
@@ -500,6 +504,13 @@ class UNetHIP(nn.Module):
         """grads of y = x W^T + b : accumulates dW, db; returns dx."""
         m = self.M(key + '.weight')
         M = x.shape[0]
+        if _DGRAD_FIRST and need_dx:   # experiment (DA_DGRAD_FIRST=1): see the note on the order below
+            dx = dx_out if dx_out is not None else self._bf(M, m.C)
+            ops.gemm_nt(dy, m.wt, dx, Geom.linear(M))
+            self._wgrad(dy, x, m.gw, Geom.linear(M), dbias=self.V(key + '.bias').g if bias else None, scratch=self._scratch)
+            return dx
+        # weight gradient FIRST, data gradient last: dx is what the next backward launch reads, and written last it is the
+        # tensor that launch finds in the 256 MB Infinity Cache (the other order measured slower in the step, DESIGN A.0)
         self._wgrad(dy, x, m.gw, Geom.linear(M), dbias=self.V(key + '.bias').g if bias else None,
                           scratch=self._scratch)
         if not need_dx:
