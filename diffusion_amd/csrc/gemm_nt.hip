@@ -260,6 +260,7 @@ extern int g_nt_persist_conv;
 extern int g_nt_de;
 extern int g_grad_overwrite;
 extern int g_attn_fused_bwd;  // attention.hip
+extern int g_tn_ring;  // gemm_tn_v2.hip
 extern int g_gn_resident, g_gn_resident_form, g_gn_resident_min_slab;  // norms.hip
 int da_usable_cus(int cus);
 static int g_nt_variant = 0;
@@ -380,6 +381,11 @@ extern "C" int da_set_option(const char* key, int value) {
   }
   if (key && !strcmp(key, "attn_fused_bwd")) {
     g_attn_fused_bwd = value;
+    return DA_OK;
+  }
+  if (key && !strcmp(key, "gemm_tn_ring")) {
+    if (value != 0 && value != 4 && value != 5) return DA_ERR_SHAPE;
+    g_tn_ring = value;
     return DA_OK;
   }
   if (key && !strcmp(key, "gemm_nt_stream_lw")) {

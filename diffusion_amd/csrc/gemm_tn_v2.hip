@@ -17,6 +17,7 @@
 
 int da_usable_cus(int cus);  // gemm_nt_v2.hip: #CUs less da_set_option("reserve_cus")
 extern int g_grad_overwrite;  // gemm_tn.hip
+int g_tn_ring = 0;  // da_set_option("gemm_tn_ring", 0 | 4 | 5): ring depth of the linear-layer form (gemm_tn2_kernel, RING)
 
 // CT (template flag of the kernel): the products are taken TRANSPOSED (X fragment as the first MFMA operand): a lane's four
 // accumulator registers of a tile are then four consecutive k' of one n, and the epilogue touches the 320 x 192 fp32 tile
@@ -69,7 +70,14 @@ DEVINL void glds16_tn(const void* gsrc, char* lds_dst) {
 // arithmetic: dY loads are uniform base + a constant lane offset, X loads add one select on a precomputed validity
 // mask.  The generic path (strided / upsampled gathers, ragged M) recomputes coordinates each step: ~105 VALU
 // instructions per step that run on every wave with the matrix pipe idle.
-template <int T2_BK, bool FAST, bool CT>
+//
+// RING (round 4; 0 = the two-stage form above): the linear layers (ksize 1, no gather, no border) stream operands that no
+// other workgroup of the XCD has just fetched, and with ONE 64-pixel stage in flight behind a vmcnt(0) barrier a step lasts
+// as long as a loaded HBM round trip (2.7-2.9 us against 0.8 us of MFMA: 16384x1280x1280 ran 76 us for 24 us of matrix
+// work).  This form keeps RING - 1 half-stages (32 pixels = one MFMA K-step, 32 KB) in flight in a ring of RING slots
+// behind COUNTED vmcnt waits: waves 0-4 request the 20 dY pieces of a half, waves 5-7 the 12 X pieces (4 per wave, so one
+// count fits all), one barrier per half.  Same products in the same order: bit-identical to RING = 0.
+template <int T2_BK, bool FAST, bool CT, int RING = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   constexpr int T2_SB = T2_BK * 2;
   constexpr int T2_B_BYTES = T2_MS * T2_SB;
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   // the uniform base sits pad*(Win+1) source pixels below the block's first one, so every lane offset is >= 0
   const long x_margin = (long)pad * (p.Win + 1);
   const long x_base0 = ((long)(m_begin / T2_MS) * src_step - x_margin) * p.ldx;
-  if constexpr (FAST) {
+  if constexpr (FAST && RING == 0) {
 #pragma unroll
     for (int j = 0; j < T2_AJ; ++j) {
       const int ci = (wave * T2_AJ + j) * 64 + lane;
@@ -293,9 +301,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
   // make the compiler wait for the DMA just issued), then two counted waits: the dY fragments + the first half of the
   // X fragments, 15 (+5 bias) MFMAs, the second half, 15 MFMAs.
   const unsigned smem_off = lds_offset(smem);
-  auto compute_half = [&](int stage, int ms) {
-    const unsigned Ab = smem_off + stage * T2_STAGE;
-    const unsigned Bb = Ab + T2_A_BYTES;
+  auto compute_half_at = [&](const unsigned Ab, const unsigned Bb, int ms) {
     const int r0 = ms * 32 + 4 * g + q, r1 = r0 + 16;
     short4v ta0[5], ta1[5], tb0[JT], tb1[JT];
 #pragma unroll
@@ -357,9 +363,57 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     }
   };
 
-  // DMA issue of the next stage between the two MFMA halves (all waves leave the barrier together: issuing first
-  // would idle every SIMD's matrix pipe during the address arithmetic)
-  if constexpr (FAST) {
+  auto compute_half = [&](int stage, int ms) {
+    const unsigned Ab = smem_off + stage * T2_STAGE;
+    compute_half_at(Ab, Ab + T2_A_BYTES, ms);
+  };
+
+  if constexpr (RING > 0) {
+    static_assert(!RING || (FAST && T2_BK == 192), "ring form: linear layers on the FAST path, 4 pieces per wave and half");
+    constexpr int HALF_A = 32 * T2_SA, HALF = HALF_A + 32 * T2_SB;  // 20 KB of dY + 12 KB of X = 32 pixels
+    const int nh = (m_end - m_begin) >> 5;  // FAST: M % 64 == 0 and splits are whole stages
+    const bool is_a = wave < 5;
+    unsigned off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (is_a) {
+        const int ci = (wave * 4 + j) * 64 + lane;
+        const int row = ci / 40, pc = ci - row * 40;
+        const int n = min(n0 + (pc ^ swA(row)) * 8, p.N - 8);  // columns past N / Kt: clamped (never stored / never reduced)
+        off[j] = (unsigned)(row * (int)p.lddy + n);
+      } else {
+        const int ci = ((wave - 5) * 4 + j) * 64 + lane;
+        const int row = ci / C16B, pc = ci - row * C16B;
+        const int kk = min(k0 + (pc ^ swB<T2_BK>(row)) * 8, p.Kt - 8);
+        off[j] = (unsigned)(row * (int)p.ldx + kk);
+      }
+    }
+    const bf16* src = is_a ? p.dY + (long)m_begin * p.lddy : p.X + (long)m_begin * p.ldx;
+    const long hstride = 32 * (is_a ? p.lddy : p.ldx);
+    char* dst0 = smem + (is_a ? wave * 4096 : HALF_A + (wave - 5) * 4096);
+    int h_issue = 0, slot_issue = 0;
+    auto issue_half = [&]() {
+      const bf16* base = src + (h_issue < nh ? h_issue : 0) * hstride;  // past the end: half 0 again, into a free slot
+      char* dst = dst0 + slot_issue * HALF;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) glds16_tn(base + off[j], dst + j * 1024);
+      ++h_issue;
+      slot_issue = slot_issue + 1 == RING ? 0 : slot_issue + 1;
+    };
+#pragma unroll
+    for (int h = 0; h < RING - 1; ++h) issue_half();
+    int slot = 0;
+    for (int h = 0; h < nh; ++h) {
+      // my pieces of half h have landed (RING - 2 younger halves of 4 pieces stay in flight); behind the barrier
+      // everybody's have, and everybody has read half h - 1 out of the slot the next request overwrites
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (RING - 2)) : "memory");
+      issue_half();
+      const unsigned Ab = smem_off + slot * HALF;
+      compute_half_at(Ab, Ab + HALF_A, 0);
+      slot = slot + 1 == RING ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail requests write LDS: not past the end of the workgroup
+  } else if constexpr (FAST) {
     issue_fast(0, true);
     __syncthreads();
     for (int t = 0; t < nsteps; ++t) {  // one basic block: no branch around the issue
@@ -559,8 +613,31 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
     if (hipMemsetAsync(p.dW, 0, (size_t)p.N * p.Kt * sizeof(float), stream) != hipSuccess) return DA_ERR_LAUNCH;
     if (p.dbias && hipMemsetAsync(p.dbias, 0, (size_t)p.N * sizeof(float), stream) != hipSuccess) return DA_ERR_LAUNCH;
   }
-  if (p.splits == 1) hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST, true>), dim3(tiles), dim3(512), SMEM, stream, p);
-  else hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST, false>), dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
+  bool ring_done = false;
+  if constexpr (FAST && BK == 192) {
+    // the ring form (see the kernel's template comment): linear layers only
+    if (g_tn_ring && p.ksize == 1 && p.mode == 0 && p.Hin == p.Hout && p.Win == p.Wout && p.N % 8 == 0 && p.Kt % 8 == 0 && p.N >= 8 &&
+        p.Kt >= 8 && 64 * p.lddy < (1L << 31) && 64 * p.ldx < (1L << 31)) {
+      static unsigned long long ring_attr[4] = {0, 0, 0, 0};
+      const dim3 grid(p.splits == 1 ? tiles : tiles * p.splits);
+#define TN2_RING(R, CTV, slot)                                                                                              \
+  {                                                                                                                       \
+    if (da_ensure_dyn_smem((const void*)gemm_tn2_kernel<BK, FAST, CTV, R>, R * 32768, &ring_attr[slot]) != DA_OK) return DA_ERR_LAUNCH; \
+    hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST, CTV, R>), grid, dim3(512), R * 32768, stream, p);                          \
+  }
+      if (g_tn_ring >= 5) {
+        if (p.splits == 1) TN2_RING(5, true, 0) else TN2_RING(5, false, 1)
+      } else {
+        if (p.splits == 1) TN2_RING(4, true, 2) else TN2_RING(4, false, 3)
+      }
+#undef TN2_RING
+      ring_done = true;
+    }
+  }
+  if (!ring_done) {
+    if (p.splits == 1) hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST, true>), dim3(tiles), dim3(512), SMEM, stream, p);
+    else hipLaunchKernelGGL((gemm_tn2_kernel<BK, FAST, false>), dim3(tiles * p.splits), dim3(512), SMEM, stream, p);
+  }
   DA_CHECK_LAUNCH();
   if (p.slab) {
     const long total = (long)p.N * (p.Kt >> 2);

@@ -517,6 +517,48 @@ def test_wgrad_v2_split_workspace(ops, dev):
         ops.SPLITK_WS = old
 
 
+@pytest.mark.parametrize('ring', [4, 5])
+@pytest.mark.parametrize('M,N,K', [(16384, 1280, 1280), (65536, 320, 320), (8192, 328, 200), (4096, 10240, 1536), (1024, 320, 640), (2048, 64, 64)])
+def test_wgrad_ring_form_equals_two_stage_form(ops, dev, ring, M, N, K):
+    """gemm_tn2_kernel RING (linear layers: ring of 32-pixel half-stages behind counted vmcnt waits,
+    da_set_option('gemm_tn_ring', 4 | 5)) against the two-stage form (0): the same products in the same order ->
+    BIT-identical dW and dbias; split tiles through slabs, unsplit tiles (10240 x 1536 = 256 tiles), ragged N / K' (clamped
+    columns), the atomic fallback without a workspace on a shape of one split, strided operands, accumulate and overwrite."""
+    dy = rnd(M, N + 16, dev=dev, seed=1, scale=0.1).to(BF)[:, 8:8 + N]; x = rnd(M, K + 8, dev=dev, seed=2).to(BF)[:, :K]
+    old = ops.SPLITK_WS
+
+    def run():
+        outs = []
+        for ws in (torch.empty(40 * 1024 * 1024, device=dev, dtype=torch.float32), None):
+            if ws is None and M > 8192:
+                continue        # no workspace: atomics (order-dependent) unless the tile has one split
+            ops.SPLITK_WS = ws
+            for ow in (0, 1):
+                ops.set_option('grad_overwrite', ow)
+                dW = torch.full((N, K), 0.25, device=dev); db = torch.full((N,), -1.0, device=dev)
+                ops.gemm_tn_wgrad(dy, x, dW, ops.Geom.linear(M), dbias=db, scratch=torch.empty(256 * N * 2, device=dev))
+                outs += [dW, db]
+        return outs
+
+    try:
+        ops.set_option('gemm_tn_ring', 0)
+        ref = run()
+        ops.set_option('gemm_tn_ring', ring)
+        got = run()
+    finally:
+        ops.set_option('gemm_tn_ring', 0)
+        ops.set_option('grad_overwrite', 0)
+        ops.SPLITK_WS = old
+    for i, (r, g_) in enumerate(zip(ref, got)):
+        if i >= 4:              # the no-workspace pass of a split shape adds with atomics: compared by value
+            check(g_, r, tol=1e-4, what=f'ring wgrad (atomics) out {i}')
+        else:
+            assert torch.equal(r, g_), f'out {i}: max |diff| {(r - g_).abs().max().item()}'
+    check(got[0] - 0.25, dy.float().t() @ x.float(), tol=2e-3, what='ring wgrad dW')
+    check(got[1] + 1.0, dy.float().sum(0), tol=2e-3, what='ring wgrad dbias')
+    check(got[2], dy.float().t() @ x.float(), tol=2e-3, what='ring wgrad dW overwrite')
+
+
 def test_wgrad_linear_large_m(ops, dev):
     M, N, K = 5000, 136, 200
     dy = rnd(M, N, dev=dev, seed=1).to(BF)
