@@ -254,7 +254,7 @@ def main():
         if prof2:
             kern2, _, roof2, _ = kernel_table(prof2)
             second['roofline'] = roof2
-            second['kernels'] = {k: kern2[k] for k in kern2 if k.startswith(('gemm_nt2_kernel<4,5,4,4>', 'gemm_tn', 'attn'))}
+            second['kernels'] = {k: kern2[k] for k in kern2 if k.startswith(('gemm_nt2_kernel<4,5,4,4>', 'gemm_nt_ws', 'gemm_tn', 'attn'))}
 
     if rank == 0:
         ips = B * world * a.steps / dt

@@ -251,6 +251,10 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
 int da_gemm_nt_v3_try(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const void* R, long ldr,
                       int M, int N, int K, hipStream_t stream);
 extern int g_nt_stream, g_nt_stream_lw;
+// weight-stationary form of the K = 320 linears (gemm_nt_ws.hip); -1 = not a shape for it
+int da_gemm_nt_ws_try(const void* A, long lda, const void* W, const float* bias, const void* R, long ldr, void* C, long ldc,
+                      int M, int N, int K, hipStream_t stream);
+extern int g_nt_ws;
 
 extern int g_tn_variant;  // gemm_tn.hip
 extern int g_nt_korder;  // gemm_nt_v2.hip
@@ -383,6 +387,10 @@ extern "C" int da_set_option(const char* key, int value) {
     g_attn_fused_bwd = value;
     return DA_OK;
   }
+  if (key && !strcmp(key, "gemm_nt_ws")) {
+    g_nt_ws = value;
+    return DA_OK;
+  }
   if (key && !strcmp(key, "gemm_tn_ring")) {
     if (value != 0 && value != 4 && value != 5) return DA_ERR_SHAPE;
     g_tn_ring = value;
@@ -446,6 +454,10 @@ extern "C" int da_gemm_nt(const void* A, long lda, const void* W, void* C, long 
   if (Hout <= 0 || Wout <= 0 || (M % (Hout * Wout))) return DA_ERR_SHAPE;
   if (R && (ldr & 7)) return DA_ERR_SHAPE;
   if (rowbias && (ldrb & 7)) return DA_ERR_SHAPE;
+  if (g_nt_ws && g_nt_variant == 0 && ksize == 1 && mode == 0 && !out_fp32 && alpha == 1.0f && !rowbias) {
+    const int rc = da_gemm_nt_ws_try(A, lda, W, bias, R, ldr, C, ldc, M, N, K, stream);
+    if (rc >= 0) return rc;
+  }
   // linears whose K loop is short against their output: the streaming form (stores of a tile drained during the next
   // tile's K loop).  gemm_nt_stream: 0 off, 1 where it measured faster (K <= 640, enough row tiles for every CU), 2 wherever eligible
   if (g_nt_stream && g_nt_variant == 0 && ksize == 1 && mode == 0 && !out_fp32 && alpha == 1.0f && !rowbias &&

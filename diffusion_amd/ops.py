@@ -6,6 +6,7 @@ passed as ld, so column slices of wider buffers (fused QKV, concat buffers) are 
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -74,8 +75,22 @@ def _f32buf(x: torch.Tensor, min_numel: int, name='buf') -> int:
     return x.data_ptr()
 
 
+_OPTS = {}   # last value set per key (profiling labels only; the library holds the state)
+
+
 def set_option(key: str, value: int):
     _lib.call('da_set_option', key.encode(), int(value))
+    _OPTS[key] = int(value)
+
+
+def _opt(key: str, default: int) -> int:
+    if key in _OPTS:
+        return _OPTS[key]
+    for kv in filter(None, os.environ.get('DA_SET_OPTIONS', '').split(',')):
+        k, _, v = kv.partition('=')
+        if k.strip() == key:
+            return int(v)
+    return default
 
 
 class Geom:
@@ -143,6 +158,11 @@ def gemm_nt(A, W, out, g: Geom, *, bias=None, rowbias=None, residual=None, alpha
                 10: 'gemm_nt2_kernel<8,5,2,4>', 11: 'gemm_nt2_kernel<4,10,2,2>', 12: 'gemm_nt2_kernel<4,5,4,4>',
                 14: 'gemm_nt2_kernel<4,4,4,4>', 15: 'gemm_nt2_kernel<1,5,8,2,mf32>', 16: 'gemm_nt2_kernel<2,5,4,2,mf32>',
                 18: 'gemm_nt2_kernel<3,4,8,2>'}[v]
+        # the weight-stationary form takes the K = 320 linears first (da_gemm_nt_ws_try, gemm_nt_ws.hip: same conditions)
+        if (_opt('gemm_nt_ws', 1) and _opt('gemm_nt_variant', 0) == 0 and K == 320 and N % 320 == 0 and 320 <= N <= 1280
+                and M % 32 == 0 and (M // 32) * (N // 320) >= 8 * 256 and g.ksize == 1 and g.mode == 0 and not out_fp32
+                and alpha == 1.0 and rowbias is None):
+            name = 'gemm_nt_ws_kernel'
     with _Timed(name, flops, (M, N, K, g.ksize, g.mode)):
         _lib.call('da_gemm_nt', a_ptr, lda, w_ptr, c_ptr, ldc, _vec(bias, N, 'bias'), rb_ptr, ldrb, r_ptr, ldr, M, N,
                   K, Cin, g.Hin, g.Win, g.Hout, g.Wout, g.ksize, g.mode, int(out_fp32), float(alpha),

@@ -517,6 +517,47 @@ def test_wgrad_v2_split_workspace(ops, dev):
         ops.SPLITK_WS = old
 
 
+@pytest.mark.parametrize('M,N', [(65536, 320), (32768 + 32, 320), (32768 + 96, 960), (65536 + 64, 640), (32768 + 40, 320)])
+def test_gemm_nt_weight_stationary_form_equals_tiled_form(ops, dev, M, N):
+    """gemm_nt_ws.hip (K = 320 linears: the weight held in registers by four waves, activations streamed through LDS two tiles
+    ahead, direct epilogue; da_set_option('gemm_nt_ws', 1)) against the tiled form (0): same products, same order, same
+    roundings -> BIT-identical, with / without bias and residual, an in-place residual, strided views, one and several
+    320-column blocks, workgroups with 4 and 5 tiles (the pipeline's drain step on either accumulator set); M % 32 != 0 is
+    not a shape for it (the tiled form takes the call)."""
+    K = 320
+    A = rnd(M, K, dev=dev, seed=1).to(BF); W = rnd(N, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
+    bias = rnd(N, dev=dev, seed=3); R = rnd(M, N, dev=dev, seed=4).to(BF)
+    wide = rnd(M, N + 64, dev=dev, seed=5).to(BF); Awide = rnd(M, K + 64, dev=dev, seed=6).to(BF)
+
+    def run():
+        outs = []
+        for b_, r_ in ((bias, R), (None, None), (bias, None), (None, R)):
+            o = torch.full((M, N), 7.0, device=dev, dtype=BF)
+            ops.gemm_nt(A, W, o, ops.Geom.linear(M), bias=b_, residual=r_)
+            outs.append(o)
+        acc = R.clone()
+        ops.gemm_nt(A, W, acc, ops.Geom.linear(M), bias=bias, residual=acc)     # in place
+        outs.append(acc)
+        buf = torch.zeros(M, N + 64, device=dev, dtype=BF)
+        ops.gemm_nt(Awide[:, 32:32 + K], W, buf[:, 32:32 + N], ops.Geom.linear(M), residual=wide[:, 16:16 + N])   # strided A, C and R
+        outs.append(buf)
+        return outs
+
+    try:
+        ops.set_option('gemm_nt_ws', 0)
+        ref = run()
+        ops.set_option('gemm_nt_ws', 1)
+        got = run()
+    finally:
+        ops.set_option('gemm_nt_ws', 0)
+    for i, (r, g_) in enumerate(zip(ref, got)):
+        assert torch.equal(r, g_), f'form {i}: max |diff| {(r.float() - g_.float()).abs().max().item()}'
+    full = A.float() @ W.float().t()
+    check(got[0], full + bias + R.float(), what='weight-stationary linear bias+res')
+    check(got[1], full, what='weight-stationary linear plain')
+    assert (got[5][:, :32] == 0).all() and (got[5][:, 32 + N:] == 0).all()
+
+
 @pytest.mark.parametrize('ring', [4, 5])
 @pytest.mark.parametrize('M,N,K', [(16384, 1280, 1280), (65536, 320, 320), (8192, 328, 200), (4096, 10240, 1536), (1024, 320, 640), (2048, 64, 64)])
 def test_wgrad_ring_form_equals_two_stage_form(ops, dev, ring, M, N, K):

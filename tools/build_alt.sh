@@ -10,7 +10,7 @@ mkdir -p $R/tools/_ab/obj
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -I$R/include -I$R/diffusion_amd/csrc -Wno-unused-result"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c "$SRC" -o $R/tools/_ab/obj/$NAME.$B.o
 OBJS=""
-for f in gemm_nt gemm_nt_v2 gemm_nt_v3 gemm_tn gemm_tn_v2 attention norms pointwise; do
+for f in gemm_nt gemm_nt_v2 gemm_nt_v3 gemm_nt_ws gemm_tn gemm_tn_v2 attention norms pointwise; do
   if [ "$f" == "$B" ]; then OBJS="$OBJS $R/tools/_ab/obj/$NAME.$B.o"; else OBJS="$OBJS $R/diffusion_amd/csrc/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $R/tools/_ab/$NAME.so
