@@ -50,6 +50,24 @@ DEVINL u32x4 ws_load16(const void* uniform_base, unsigned byte_off) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(uniform_base) : "memory");
   return v;
 }
+// ds_read_b128 through inline asm with an immediate offset: the compiler's scheduler sinks plain LDS loads down to their
+// first use when registers are tight (every K-step then waited lgkmcnt(0) for the fragment it had just requested: 20 exposed
+// LDS round trips per tile, 1.9 us per tile for 0.76 us of MFMA); the asm form stays where it is written, one K-step ahead,
+// and is ordered with lds_wait_for<N>() (common.hpp).
+template <int OFF>
+DEVINL bf16x8 ws_lds16(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int B, int E, typename F>
+DEVINL void ws_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    ws_static_for<B + 1, E>(f);
+  }
+}
+
 DEVINL void ws_wait_vm(int n) {  // all but the n youngest vector-memory operations of this wave are complete
   switch (n) {
 #define WS_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
@@ -95,6 +113,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
 #pragma unroll
     for (int j = 0; j < WS_PIECES; ++j) glds16_ws(base + dsrc[j], dst + j * 1024);
   };
+#ifdef WS_EXP_AHOT      // timing-only build: every request re-reads the workgroup's first tile (L2-resident)
+#define WS_REQ(k) request_hot(k)
+  auto request_hot = [&](int k) {
+    const char* base = reinterpret_cast<const char*>(p.A) + (long)slot * WS_BM * p.lda * 2;
+    char* dst = smem + (k % WS_NS) * WS_STAGE + wave * (WS_PIECES * 1024);
+#pragma unroll
+    for (int j = 0; j < WS_PIECES; ++j) glds16_ws(base + dsrc[j], dst + j * 1024);
+  };
+#else
+#define WS_REQ(k) request(k)
+#endif
   // Vector-memory operations this wave issues AFTER the requests of its tile k (k >= WS_AHEAD; issued in step k - WS_AHEAD):
   // what the wait in front of tile k may leave in flight.  A step j issues, in this order: the residual loads of tile j - 1
   // (j >= 1, HASR), the requests of tile j + WS_AHEAD (while there is one), the stores of tile j - 1 (j >= 1); 5 each.
@@ -113,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
   // microseconds during which HBM would otherwise idle), then everything is waited for together
 #pragma unroll
   for (int k = 0; k < WS_AHEAD; ++k)
-    if (k < n_my) request(k);
+    if (k < n_my) WS_REQ(k);
   // ---- the resident weight fragments: W rows n0 + 80*wave + 16*jt + (lane & 15), k = 32*s + 8*(lane >> 4) .. + 7
   bf16x8 wf[5][10];
   {
@@ -168,6 +197,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
     return u32x4{s0[0], s1[0], s0[1], s1[1]};
   };
 
+  const unsigned smem_off = lds_offset(smem);
   const unsigned frag_off = (unsigned)(l15 * WS_ROWB);
   const int fsw = (lane >> 1) & 7;
   typedef accv_t acc_t[WS_MT][5];
@@ -199,50 +229,57 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
     bool requested = false;
     if constexpr (C) {
       if (k + WS_AHEAD < n_my) {
-        request(k + WS_AHEAD);
+        WS_REQ(k + WS_AHEAD);
         requested = true;
       }
     }
-    const char* sb = smem + st * WS_STAGE + frag_off;
-    auto frag = [&](int i, int s) {
-      return *reinterpret_cast<const bf16x8*>(sb + i * (16 * WS_ROWB) + (((4 * s + g4) ^ fsw) << 4));
-    };
+    // fragment (strip i, K-step s) = 16 bytes at row 16*i + (lane & 15), chunk (4*s + (lane >> 4)) ^ ((lane >> 1) & 7) of the
+    // stage: with lo = (lane >> 4) ^ (fsw & 3) and b = fsw >> 2 that is byte 16*lo + 64*(s ^ b) of the row, i.e. an even /
+    // odd base register per lane and an IMMEDIATE 64*(s & ~1) + 10240*i - no address arithmetic in the K loop
+    const unsigned fb = smem_off + (unsigned)(st * WS_STAGE) + frag_off + (unsigned)(((g4 ^ (fsw & 3)) << 4));
+    const unsigned fb_even = fb + (unsigned)((fsw >> 2) << 6), fb_odd = fb + (unsigned)((1 - (fsw >> 2)) << 6);
     char* cb = reinterpret_cast<char*>(p.C) + (long)(slot + (k - 1) * grid) * WS_BM * p.ldc * 2;
     auto piece = [&](int q) {  // q = 0..4: the finished tile's 16-byte pieces in strip order
       static_assert(WS_MT == 2, "piece table");
       constexpr int PI[5] = {0, 0, 1, 1, 1}, PP[5] = {0, 1, 0, 1, 2};
       const int i = PI[q], pj = PP[q];
       const u32x4 o = pj < 2 ? finish(prev[i][2 * pj], prev[i][2 * pj + 1], rin[i][pj]) : finish(prev[i - 1][4], prev[i][4], rin5[i >> 1]);
+#ifdef WS_EXP_NOSTORE   // timing-only build (tools/build_alt.sh): everything but the stores
+      asm volatile("" ::"v"(o));
+#else
       *reinterpret_cast<u32x4*>(cb + out_off(i, pj, p.ldc)) = o;
+#endif
     };
     bf16x8 a_cur[WS_MT], a_nxt[WS_MT];
     if constexpr (C) {
-#pragma unroll
-      for (int i = 0; i < WS_MT; ++i) a_cur[i] = frag(i, 0);
+      a_cur[0] = ws_lds16<0>(fb_even);
+      a_cur[1] = ws_lds16<16 * WS_ROWB>(fb_even);
     }
-#pragma unroll
-    for (int s = 0; s < 10; ++s) {
-      if (s == 5) {
-        if constexpr (E && HASR) {
-          // the residual has landed (only this step's requests are younger).  The registers are operands of the wait: without
-          // that tie nothing stops the compiler from scheduling their first use in front of it.
-          // ONE statement for both counts (a run-time branch between two tied statements makes the compiler join their
-          // register operands with copies - placed in front of the wait, they would read registers the loads have not filled)
-          asm volatile("s_waitcnt vmcnt(5)\n\t"
-                       "s_cmp_lg_u32 %5, 0\n\t"
-                       "s_cbranch_scc1 .Lws_r%=\n\t"
-                       "s_waitcnt vmcnt(0)\n"
-                       ".Lws_r%=:"
-                       : "+v"(rin[0][0]), "+v"(rin[0][1]), "+v"(rin[1][0]), "+v"(rin[1][1]), "+v"(rin5[0])
-                       : "s"((int)requested)
-                       : "scc", "memory");
-          static_assert(WS_PIECES == 5 && WS_MT == 2, "operands of the residual wait");
-        }
+    ws_static_for<0, 10>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+      if constexpr (s == 5 && E && HASR) {
+        // the residual has landed (only this step's requests are younger).  The registers are operands of the wait: without
+        // that tie nothing stops the compiler from scheduling their first use in front of it.  ONE statement for both counts
+        // (a run-time branch between two tied statements makes the compiler join their register operands with copies -
+        // placed in front of the wait, they would read registers the loads have not filled)
+        asm volatile("s_waitcnt vmcnt(5)\n\t"
+                     "s_cmp_lg_u32 %5, 0\n\t"
+                     "s_cbranch_scc1 .Lws_r%=\n\t"
+                     "s_waitcnt vmcnt(0)\n"
+                     ".Lws_r%=:"
+                     : "+v"(rin[0][0]), "+v"(rin[0][1]), "+v"(rin[1][0]), "+v"(rin[1][1]), "+v"(rin5[0])
+                     : "s"((int)requested)
+                     : "scc", "memory");
+        static_assert(WS_PIECES == 5 && WS_MT == 2, "operands of the residual wait");
       }
       if constexpr (C) {
-        if (s + 1 < 10) {
-#pragma unroll
-          for (int i = 0; i < WS_MT; ++i) a_nxt[i] = frag(i, s + 1);
+        if constexpr (s + 1 < 10) {
+          constexpr int OFF = 64 * ((s + 1) & ~1);
+          a_nxt[0] = ws_lds16<OFF>(((s + 1) & 1) ? fb_odd : fb_even);
+          a_nxt[1] = ws_lds16<OFF + 16 * WS_ROWB>(((s + 1) & 1) ? fb_odd : fb_even);
+          lds_wait_for<2>(a_cur[0], a_cur[1]);   // this step's fragments are here; the two just requested stay in flight
+        } else {
+          lds_wait_for<0>(a_cur[0], a_cur[1]);
         }
       }
 #pragma unroll
@@ -260,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
 #pragma unroll
         for (int i = 0; i < WS_MT; ++i) a_cur[i] = a_nxt[i];
       }
-    }
+    });
   };
 
   acc_t accA, accB;
