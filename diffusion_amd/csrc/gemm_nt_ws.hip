@@ -1,5 +1,6 @@
-// gemm_nt_ws: weight-stationary linear layer for K = 320 (the level-0 transformer width); da_set_option("gemm_nt_ws", 0 | 1), on.
-//     C[m][n] = sum_k A[m][k] * W[n][k]  (+ bias[n]) (+ R[m][n]),  bf16 in / out, fp32 accumulation,  N = 320, 640, 960, 1280
+// gemm_nt_ws: weight-stationary linear layers for K = 320 and K = 640 (the level-0 / level-1 transformer widths);
+// da_set_option("gemm_nt_ws", 0 | 1), on.   C[m][n] = sum_k A[m][k] * W[n][k]  (+ bias[n]) (+ R[m][n]),  bf16 in / out, fp32 sums.
+// Written for K = 320 (N = 320 ... 1280); the K = 640 instantiation follows at the end of this comment.
 // The tiled form (gemm_nt_v2.hip) stages a 40 KB slice of W per K-step next to the activation rows and re-reads both as MFMA
 // fragments; at K = N = 320 the whole weight is 200 KB = 200 registers per lane of FOUR waves (one per SIMD, which gives
 // each the whole 512-register file): wave w keeps the fragments of output columns 80w .. 80w+79 over all of K for the life of
@@ -13,12 +14,17 @@
 // waits leave the younger ones in flight.  Same products, same order of the K sum, same roundings as the tiled form:
 // bit-identical (tests/test_kernels_gpu.py).  Measured (profiles/r04_ab_nt_ws.txt): 262144 x 320 x 320 88 -> 72 us (4.7 TB/s of
 // its own bytes), with a residual 122 -> 97 (5.2 TB/s), 262144 x 960 x 320 234 -> 189; the step 168.8 -> 167.5 ms.
+// K = 640 (WsCfg<20, 2>, opt-in: bit 1 of the option): a workgroup holds W for 128 output columns (160 KB; wave w columns
+// 32w .. 32w+31 over all of K), the stages are 32 rows x 1280 B (40 KB, ring of four = the whole LDS, chunk XOR row & 15),
+// N = 640 is five column blocks whose workgroups share an XCD and read the activation rows through its L2.  Bit-identical
+// too, but not faster: 65536 x 640 x 640 61 us against 56 us tiled (each of its 43 tiles per workgroup costs 10 tile requests
+// and a barrier for 80 MFMAs per wave), 262144 x 640 x 640 236 against 245.
 #include <type_traits>
 #include "common.hpp"
 #include "diffusion_amd.h"
 
 int da_usable_cus(int cus);  // gemm_nt_v2.hip
-int g_nt_ws = 1;             // da_set_option("gemm_nt_ws", 0 | 1)
+int g_nt_ws = 1;             // da_set_option("gemm_nt_ws", bits): 1 = the K = 320 form (on), 2 = the K = 640 form (off: measured slower)
 
 namespace {
 
@@ -32,13 +38,26 @@ struct GemmWsParams {
   int M, N, tiles_m, nb;
 };
 
-constexpr int WS_K = 320, WS_MT = 2, WS_BM = 16 * WS_MT, WS_BN = 320, WS_ROWB = WS_K * 2, WS_STAGE = WS_BM * WS_ROWB;
+constexpr int WS_BM = 32;  // rows per tile: two 16-row MFMA strips
 #ifndef WS_NS_BUILD
 #define WS_NS_BUILD 4
 #endif
-constexpr int WS_NS = WS_NS_BUILD;  // LDS stages of 20 KB (ring); 4 / 6 / 8 measured equal (tools/build_alt.sh -DWS_NS_BUILD=n)
-constexpr int WS_PIECES = WS_STAGE / 1024 / 4;  // LDS-DMA instructions per wave and tile (5); also the residual loads and the stores
-constexpr int WS_AHEAD = WS_NS - 1;             // tiles requested ahead of the one being computed
+constexpr int WS_NS = WS_NS_BUILD;   // LDS stages (ring); 4 / 6 / 8 measured equal at K = 320 (tools/build_alt.sh -DWS_NS_BUILD=n)
+constexpr int WS_AHEAD = WS_NS - 1;  // tiles requested ahead of the one being computed
+
+// KS = K / 32 MFMA K-steps, NT = 16-column MFMA tiles per wave
+template <int KS, int NT>
+struct WsCfg {
+  static constexpr int K = 32 * KS, BN = 64 * NT, ROWB = 64 * KS, STAGE = WS_BM * ROWB;
+  static constexpr int PD = STAGE / 4096;          // LDS-DMA instructions per wave and tile
+  static constexpr int NPJ = NT / 2, ODD = NT & 1;  // column-tile pairs per strip; a last tile paired across the two strips
+  static constexpr int PO = 2 * NPJ + ODD;         // 16-byte output pieces per lane and tile (= residual loads = stores)
+  // source-side XOR of the 16-byte chunk index that makes ds_read_b128 of 16 consecutive rows conflict-free: rows of an odd
+  // number of 128-byte halves (640 B) need three bits, (row >> 1) & 7; rows of whole 256-byte bank rows (1280 B) four, row & 15
+  static constexpr int SWB = (ROWB % 256 == 0) ? 4 : 3;
+  static constexpr int PER = 1 << (SWB - 2);       // fragment base registers per lane (K-steps s, s + PER, ... share one)
+  static_assert(STAGE % 4096 == 0 && WS_NS * STAGE <= 160 * 1024 && (ROWB / 16) % (1 << SWB) % 8 == 0, "stage geometry");
+};
 
 DEVINL void glds16_ws(const void* gsrc, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -71,109 +90,117 @@ DEVINL void ws_static_for(F&& f) {
 DEVINL void ws_wait_vm(int n) {  // all but the n youngest vector-memory operations of this wave are complete
   switch (n) {
 #define WS_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    WS_W(5) WS_W(10) WS_W(15) WS_W(20) WS_W(25) WS_W(30) WS_W(35) WS_W(40) WS_W(45) WS_W(50) WS_W(55) WS_W(60)
+#define WS_W10(D) WS_W(D##0) WS_W(D##1) WS_W(D##2) WS_W(D##3) WS_W(D##4) WS_W(D##5) WS_W(D##6) WS_W(D##7) WS_W(D##8) WS_W(D##9)
+    WS_W(1) WS_W(2) WS_W(3) WS_W(4) WS_W(5) WS_W(6) WS_W(7) WS_W(8) WS_W(9)
+    WS_W10(1) WS_W10(2) WS_W10(3) WS_W10(4) WS_W10(5) WS_W(60)
+#undef WS_W10
 #undef WS_W
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // never more than it is safe to leave
   }
 }
 
-template <bool HASR>
+template <int KS, int NT, bool HASR>
 __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
+  typedef WsCfg<KS, NT> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // WS_NS stages of 32 activation rows
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
   typedef float accv_t __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g4 = lane >> 4, l15 = lane & 15;
-  // Workgroup -> (slot, column block).  A slot is a walk over the row tiles slot, slot + grid, ...; with N = nb x 320 the nb
+  // Workgroup -> (slot, column block).  A slot is a walk over the row tiles slot, slot + grid, ...; with N = nb x BN the nb
   // workgroups of a slot hold different weight columns and read the SAME activation rows, so they are placed on one XCD
   // (workgroup ids equal mod 8 share an XCD and its L2): per XCD gridDim.x / 8 workgroups = spx slots x nb column blocks,
-  // the remainder (2 of 32 at nb = 3) exits - the rows are then fetched from HBM once, not nb times.
+  // the remainder (2 of 32 at nb = 3 or 5) exits - the rows are then fetched from HBM once, not nb times.
   const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
   const int spx = ((int)gridDim.x >> 3) / p.nb;
   if (idx >= spx * p.nb) return;
-  const int n0 = (idx % p.nb) * WS_BN;
+  const int n0 = (idx % p.nb) * G::BN;
   const int slot = xcd * spx + idx / p.nb;
   const int grid = 8 * spx;
   if (slot >= p.tiles_m) return;
   const int n_my = (p.tiles_m - slot + grid - 1) / grid;  // tiles of this workgroup: slot + k*grid
 
-  // ---- tile requests: piece j of this wave covers LDS bytes (wave*10 + j)*1024 + lane*16 of the stage image
-  // [row][640 B], physical 16-byte chunk pc of row r holding logical chunk pc ^ ((r >> 1) & 7) (conflict-free ds_read_b128)
-  unsigned dsrc[WS_PIECES];
+  // ---- tile requests: piece j of this wave covers LDS bytes (wave*PD + j)*1024 + lane*16 of the stage image [row][ROWB],
+  // physical 16-byte chunk pc of row r holding logical chunk pc ^ swz(r)
+  unsigned dsrc[G::PD];
 #pragma unroll
-  for (int j = 0; j < WS_PIECES; ++j) {
-    const int byte = (wave * WS_PIECES + j) * 1024 + lane * 16;
-    const int row = byte / WS_ROWB, pc = (byte - row * WS_ROWB) >> 4;
-    dsrc[j] = (unsigned)row * (unsigned)(p.lda * 2) + (unsigned)((pc ^ ((row >> 1) & 7)) << 4);
+  for (int j = 0; j < G::PD; ++j) {
+    const int byte = (wave * G::PD + j) * 1024 + lane * 16;
+    const int row = byte / G::ROWB, pc = (byte - row * G::ROWB) >> 4;
+    const int swz = G::SWB == 3 ? (row >> 1) & 7 : row & 15;
+    dsrc[j] = (unsigned)row * (unsigned)(p.lda * 2) + (unsigned)((pc ^ swz) << 4);
   }
   auto request = [&](int k) {  // k-th tile of this workgroup -> stage k % WS_NS
     const char* base = reinterpret_cast<const char*>(p.A) + (long)(slot + k * grid) * WS_BM * p.lda * 2;
-    char* dst = smem + (k % WS_NS) * WS_STAGE + wave * (WS_PIECES * 1024);
+    char* dst = smem + (k % WS_NS) * G::STAGE + wave * (G::PD * 1024);
 #pragma unroll
-    for (int j = 0; j < WS_PIECES; ++j) glds16_ws(base + dsrc[j], dst + j * 1024);
+    for (int j = 0; j < G::PD; ++j) glds16_ws(base + dsrc[j], dst + j * 1024);
   };
 #ifdef WS_EXP_AHOT      // timing-only build: every request re-reads the workgroup's first tile (L2-resident)
 #define WS_REQ(k) request_hot(k)
   auto request_hot = [&](int k) {
     const char* base = reinterpret_cast<const char*>(p.A) + (long)slot * WS_BM * p.lda * 2;
-    char* dst = smem + (k % WS_NS) * WS_STAGE + wave * (WS_PIECES * 1024);
+    char* dst = smem + (k % WS_NS) * G::STAGE + wave * (G::PD * 1024);
 #pragma unroll
-    for (int j = 0; j < WS_PIECES; ++j) glds16_ws(base + dsrc[j], dst + j * 1024);
+    for (int j = 0; j < G::PD; ++j) glds16_ws(base + dsrc[j], dst + j * 1024);
   };
 #else
 #define WS_REQ(k) request(k)
 #endif
   // Vector-memory operations this wave issues AFTER the requests of its tile k (k >= WS_AHEAD; issued in step k - WS_AHEAD):
-  // what the wait in front of tile k may leave in flight.  A step j issues, in this order: the residual loads of tile j - 1
-  // (j >= 1, HASR), the requests of tile j + WS_AHEAD (while there is one), the stores of tile j - 1 (j >= 1); 5 each.
+  // what the wait in front of tile k may leave in flight.  A step j issues, in this order: the PO residual loads of tile j - 1
+  // (j >= 1, HASR), the PD requests of tile j + WS_AHEAD (while there is one), the PO stores of tile j - 1 (j >= 1).
   // (A pure function of k on purpose: running counters captured by the step lambda ended up in scratch memory, and every
   // scratch load comes with s_waitcnt vmcnt(0).)
   auto after_requests_of = [&](int k) {
     const int j0 = k - WS_AHEAD;
-    int n = j0 >= 1 ? WS_PIECES : 0;
+    int n = j0 >= 1 ? G::PO : 0;
 #pragma unroll
     for (int d = 1; d < WS_AHEAD; ++d)
-      n += (HASR ? WS_PIECES : 0) + (j0 + d + WS_AHEAD < n_my ? WS_PIECES : 0) + WS_PIECES;
+      n += (HASR ? G::PO : 0) + (j0 + d + WS_AHEAD < n_my ? G::PD : 0) + G::PO;
     return n < 60 ? n : 60;  // the counter has 6 bits; leaving fewer in flight than allowed is always safe
   };
 
-  // the first two tiles are requested BEFORE the 200 KB of weight fragments (every workgroup fetches them at once - a few
+  // the first tiles are requested BEFORE the 160-200 KB of weight fragments (every workgroup fetches them at once - a few
   // microseconds during which HBM would otherwise idle), then everything is waited for together
 #pragma unroll
   for (int k = 0; k < WS_AHEAD; ++k)
     if (k < n_my) WS_REQ(k);
-  // ---- the resident weight fragments: W rows n0 + 80*wave + 16*jt + (lane & 15), k = 32*s + 8*(lane >> 4) .. + 7
-  bf16x8 wf[5][10];
+  // ---- the resident weight fragments: W rows n0 + 16*NT*wave + 16*jt + (lane & 15), k = 32*s + 8*(lane >> 4) .. + 7
+  bf16x8 wf[NT][KS];
   {
-    const bf16* wp = p.W + (long)(n0 + 80 * wave + l15) * WS_K + 8 * g4;
+    const bf16* wp = p.W + (long)(n0 + 16 * NT * wave + l15) * G::K + 8 * g4;
 #pragma unroll
-    for (int jt = 0; jt < 5; ++jt)
+    for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-      for (int s = 0; s < 10; ++s) wf[jt][s] = ld8(wp + (long)(16 * jt) * WS_K + 32 * s);
+      for (int s = 0; s < KS; ++s) wf[jt][s] = ld8(wp + (long)(16 * jt) * G::K + 32 * s);
   }
-  // bias of this lane's accumulator columns n0 + 80*wave + 16*jt + 4*(lane >> 4) + e: the start value of every K sum
-  accv_t bv[5];
+  // bias of this lane's accumulator columns n0 + 16*NT*wave + 16*jt + 4*(lane >> 4) + e: the start value of every K sum
+  accv_t bv[NT];
 #pragma unroll
-  for (int jt = 0; jt < 5; ++jt)
+  for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bv[jt][e] = p.bias ? p.bias[n0 + 80 * wave + 16 * jt + 4 * g4 + e] : 0.f;
+    for (int e = 0; e < 4; ++e) bv[jt][e] = p.bias ? p.bias[n0 + 16 * NT * wave + 16 * jt + 4 * g4 + e] : 0.f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the counted waits below start from zero
   // ... and the compiler's own bookkeeping too: redefined here, the fragments are no pending loads to it (it would otherwise
   // wait vmcnt(0) for them in front of the first product - behind the tile requests in flight)
 #pragma unroll
-  for (int jt = 0; jt < 5; ++jt) {
+  for (int jt = 0; jt < NT; ++jt) {
 #pragma unroll
-    for (int s = 0; s < 10; ++s) asm volatile("" : "+v"(wf[jt][s]));
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[jt][s]));
     asm volatile("" : "+v"(bv[jt]));
   }
 
-  // ---- this lane's 16 bytes of the output tile (the direct epilogue of gemm_nt_v2.hip with wm = 0, MT = 4, wn = wave, NT = 5):
-  // pieces (strip i, column pair pj = 0, 1); pj = 2: the fifth column tile of the strip pair (i - 1, i)
-  const int lq = g4 & 1, lcol = 80 * wave + 8 * (lane >> 5);
-  auto out_off = [&](int i, int pj, long ld) {
-    const int row = (pj < 2) ? l15 + 16 * i : l15 + 16 * (i - 1 + lq);
-    const int col = (pj < 2) ? lcol + 32 * pj + 16 * lq : lcol + 64;
+  // ---- this lane's 16 bytes of the output tile (the direct epilogue of gemm_nt_v2.hip with wm = 0, MT = 2, wn = wave):
+  // pieces q = (strip i, column pair pj): q < NPJ -> (0, q), q < 2*NPJ -> (1, q - NPJ), q = 2*NPJ (NT odd) -> the last column
+  // tile of both strips
+  const int lq = g4 & 1, lcol = 16 * NT * wave + 8 * (lane >> 5);
+  auto out_off = [&](int q, long ld) {
+    const bool odd = q >= 2 * G::NPJ;
+    const int i = q < G::NPJ ? 0 : 1, pj = q < G::NPJ ? q : q - G::NPJ;
+    const int row = odd ? l15 + 16 * lq : l15 + 16 * i;
+    const int col = odd ? lcol + 16 * (NT - 1) : lcol + 32 * pj + 16 * lq;
     return (unsigned)row * (unsigned)(ld * 2) + (unsigned)(n0 + col) * 2u;
   };
   auto finish = [&](accv_t a, accv_t b, const u32x4 r) {
@@ -197,17 +224,20 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
     return u32x4{s0[0], s1[0], s0[1], s1[1]};
   };
 
+  // fragment (strip i, K-step s) = 16 bytes at row 16*i + (lane & 15), chunk (4*s + (lane >> 4)) ^ swz of the stage, swz the
+  // lane's row swizzle.  With lo = (lane >> 4) ^ (swz & 3) and h = swz >> 2 that is byte 16*lo + 64*((s % PER) ^ h) +
+  // 64*PER*(s / PER) of the row: PER base registers per lane and an IMMEDIATE - no address arithmetic in the K loop
   const unsigned smem_off = lds_offset(smem);
-  const unsigned frag_off = (unsigned)(l15 * WS_ROWB);
-  const int fsw = (lane >> 1) & 7;
-  typedef accv_t acc_t[WS_MT][5];
+  const int fsw = G::SWB == 3 ? (lane >> 1) & 7 : l15;
+  const unsigned frag_off = (unsigned)(l15 * G::ROWB) + (unsigned)((g4 ^ (fsw & 3)) << 4);
+  typedef accv_t acc_t[2][NT];
   typedef std::integral_constant<bool, true> yes_t;
   typedef std::integral_constant<bool, false> no_t;
 
   // One step of the software pipeline: the products of tile k (-> cur) run beside the epilogue of tile k - 1 (<- prev): a
   // single wave per SIMD has nobody else to fill the gaps between its MFMAs, so the conversion, shuffle and store
-  // instructions of the finished tile are placed between the products of the next one (second half of its K loop; the
-  // residual of the finished tile is requested at the start of the step and waited for at half time).
+  // instructions of the finished tile are placed between the products of the next one (the last PO K-steps; the residual of
+  // the finished tile is requested at the start of the step and waited for in front of the first piece).
   auto step = [&](acc_t& cur, acc_t& prev, auto do_compute, auto do_epi, const int k) {
     constexpr bool C = decltype(do_compute)::value, E = decltype(do_epi)::value;
     const int st = k % WS_NS;
@@ -216,16 +246,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
       __builtin_amdgcn_s_barrier();  // everybody's pieces of tile k are in LDS; everybody is done with the stage requested next
       asm volatile("" ::: "memory");
     }
-    u32x4 rin[WS_MT][2], rin5[WS_MT / 2];
+    u32x4 rin[G::PO];
     if constexpr (E && HASR) {
       const char* rb = reinterpret_cast<const char*>(p.R) + (long)(slot + (k - 1) * grid) * WS_BM * p.ldr * 2;
 #pragma unroll
-      for (int i = 0; i < WS_MT; ++i) {
-#pragma unroll
-        for (int pj = 0; pj < 2; ++pj) rin[i][pj] = ws_load16(rb, out_off(i, pj, p.ldr));
-        if (i & 1) rin5[i >> 1] = ws_load16(rb, out_off(i, 2, p.ldr));
-      }
+      for (int q = 0; q < G::PO; ++q) rin[q] = ws_load16(rb, out_off(q, p.ldr));
     }
+    // (the PD requests in one block: spread one per K-step over the products - each behind its own uniform branch - the
+    // step measured 7-13 % slower)
     bool requested = false;
     if constexpr (C) {
       if (k + WS_AHEAD < n_my) {
@@ -233,69 +261,76 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
         requested = true;
       }
     }
-    // fragment (strip i, K-step s) = 16 bytes at row 16*i + (lane & 15), chunk (4*s + (lane >> 4)) ^ ((lane >> 1) & 7) of the
-    // stage: with lo = (lane >> 4) ^ (fsw & 3) and b = fsw >> 2 that is byte 16*lo + 64*(s ^ b) of the row, i.e. an even /
-    // odd base register per lane and an IMMEDIATE 64*(s & ~1) + 10240*i - no address arithmetic in the K loop
-    const unsigned fb = smem_off + (unsigned)(st * WS_STAGE) + frag_off + (unsigned)(((g4 ^ (fsw & 3)) << 4));
-    const unsigned fb_even = fb + (unsigned)((fsw >> 2) << 6), fb_odd = fb + (unsigned)((1 - (fsw >> 2)) << 6);
+    unsigned fbase[G::PER];
+#pragma unroll
+    for (int m = 0; m < G::PER; ++m) fbase[m] = smem_off + (unsigned)(st * G::STAGE) + frag_off + (unsigned)((m ^ (fsw >> 2)) << 6);
     char* cb = reinterpret_cast<char*>(p.C) + (long)(slot + (k - 1) * grid) * WS_BM * p.ldc * 2;
-    auto piece = [&](int q) {  // q = 0..4: the finished tile's 16-byte pieces in strip order
-      static_assert(WS_MT == 2, "piece table");
-      constexpr int PI[5] = {0, 0, 1, 1, 1}, PP[5] = {0, 1, 0, 1, 2};
-      const int i = PI[q], pj = PP[q];
-      const u32x4 o = pj < 2 ? finish(prev[i][2 * pj], prev[i][2 * pj + 1], rin[i][pj]) : finish(prev[i - 1][4], prev[i][4], rin5[i >> 1]);
+    auto piece = [&](int q) {  // the finished tile's 16-byte pieces in strip order
+      const bool odd = q >= 2 * G::NPJ;
+      const int i = q < G::NPJ ? 0 : 1, pj = q < G::NPJ ? q : q - G::NPJ;
+      const u32x4 o = odd ? finish(prev[0][NT - 1], prev[1][NT - 1], rin[q]) : finish(prev[i][2 * pj], prev[i][2 * pj + 1], rin[q]);
 #ifdef WS_EXP_NOSTORE   // timing-only build (tools/build_alt.sh): everything but the stores
       asm volatile("" ::"v"(o));
 #else
-      *reinterpret_cast<u32x4*>(cb + out_off(i, pj, p.ldc)) = o;
+      *reinterpret_cast<u32x4*>(cb + out_off(q, p.ldc)) = o;
 #endif
     };
-    bf16x8 a_cur[WS_MT], a_nxt[WS_MT];
+    bf16x8 a_cur[2], a_nxt[2];
     if constexpr (C) {
-      a_cur[0] = ws_lds16<0>(fb_even);
-      a_cur[1] = ws_lds16<16 * WS_ROWB>(fb_even);
+      a_cur[0] = ws_lds16<0>(fbase[0]);
+      a_cur[1] = ws_lds16<16 * G::ROWB>(fbase[0]);
     }
-    ws_static_for<0, 10>([&](auto S) {
+    ws_static_for<0, KS>([&](auto S) {
       constexpr int s = decltype(S)::value;
-      if constexpr (s == 5 && E && HASR) {
+      if constexpr (s == KS - G::PO && E && HASR) {
         // the residual has landed (only this step's requests are younger).  The registers are operands of the wait: without
         // that tie nothing stops the compiler from scheduling their first use in front of it.  ONE statement for both counts
         // (a run-time branch between two tied statements makes the compiler join their register operands with copies -
         // placed in front of the wait, they would read registers the loads have not filled)
-        asm volatile("s_waitcnt vmcnt(5)\n\t"
-                     "s_cmp_lg_u32 %5, 0\n\t"
-                     "s_cbranch_scc1 .Lws_r%=\n\t"
-                     "s_waitcnt vmcnt(0)\n"
-                     ".Lws_r%=:"
-                     : "+v"(rin[0][0]), "+v"(rin[0][1]), "+v"(rin[1][0]), "+v"(rin[1][1]), "+v"(rin5[0])
-                     : "s"((int)requested)
-                     : "scc", "memory");
-        static_assert(WS_PIECES == 5 && WS_MT == 2, "operands of the residual wait");
+        static_assert(G::PO == 5 || G::PO == 2, "operands of the residual wait");
+        if constexpr (G::PO == 5)
+          asm volatile("s_waitcnt vmcnt(%6)\n\t"
+                       "s_cmp_lg_u32 %5, 0\n\t"
+                       "s_cbranch_scc1 .Lws_r%=\n\t"
+                       "s_waitcnt vmcnt(0)\n"
+                       ".Lws_r%=:"
+                       : "+v"(rin[0]), "+v"(rin[1]), "+v"(rin[2]), "+v"(rin[3]), "+v"(rin[G::PO - 1])
+                       : "s"(__builtin_amdgcn_readfirstlane((int)requested)), "n"(G::PD)
+                       : "scc", "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%3)\n\t"
+                       "s_cmp_lg_u32 %2, 0\n\t"
+                       "s_cbranch_scc1 .Lws_r%=\n\t"
+                       "s_waitcnt vmcnt(0)\n"
+                       ".Lws_r%=:"
+                       : "+v"(rin[0]), "+v"(rin[G::PO - 1])
+                       : "s"(__builtin_amdgcn_readfirstlane((int)requested)), "n"(G::PD)
+                       : "scc", "memory");
       }
       if constexpr (C) {
-        if constexpr (s + 1 < 10) {
-          constexpr int OFF = 64 * ((s + 1) & ~1);
-          a_nxt[0] = ws_lds16<OFF>(((s + 1) & 1) ? fb_odd : fb_even);
-          a_nxt[1] = ws_lds16<OFF + 16 * WS_ROWB>(((s + 1) & 1) ? fb_odd : fb_even);
+        if constexpr (s + 1 < KS) {
+          constexpr int OFF = 64 * G::PER * ((s + 1) / G::PER);
+          a_nxt[0] = ws_lds16<OFF>(fbase[(s + 1) % G::PER]);
+          a_nxt[1] = ws_lds16<OFF + 16 * G::ROWB>(fbase[(s + 1) % G::PER]);
           lds_wait_for<2>(a_cur[0], a_cur[1]);   // this step's fragments are here; the two just requested stay in flight
         } else {
           lds_wait_for<0>(a_cur[0], a_cur[1]);
         }
       }
 #pragma unroll
-      for (int i = 0; i < WS_MT; ++i) {
+      for (int i = 0; i < 2; ++i) {
         if constexpr (C) {
 #pragma unroll
-          for (int jt = 0; jt < 5; ++jt)
+          for (int jt = 0; jt < NT; ++jt)
             cur[i][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jt][s], a_cur[i], s == 0 ? bv[jt] : cur[i][jt], 0, 0, 0);
         }
         if constexpr (E) {
-          if (s >= 5 && i == WS_MT - 1) piece(s - 5);
+          if (s >= KS - G::PO && i == 1) piece(s - (KS - G::PO));
         }
       }
       if constexpr (C) {
-#pragma unroll
-        for (int i = 0; i < WS_MT; ++i) a_cur[i] = a_nxt[i];
+        a_cur[0] = a_nxt[0];
+        a_cur[1] = a_nxt[1];
       }
     });
   };
@@ -313,35 +348,42 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+template <int KS, int NT>
+int launch_ws(GemmWsParams p, int N, int cus, hipStream_t stream) {
+  typedef WsCfg<KS, NT> G;
+  const int nb = N / G::BN;
+  if (nb < 1 || nb > 8 || N % G::BN) return -1;
+  if ((long)p.tiles_m * nb < 8L * cus) return -1;  // each workgroup loads 160-200 KB of W before its first 20-40 KB tile
+  p.nb = nb;
+  const int gx = (cus / 8) * 8;  // whole rounds of the 8 XCDs (see the kernel's slot mapping)
+  if (gx < 8 * nb) return -1;
+  constexpr int SMEM = WS_NS * G::STAGE;
+  static unsigned long long attr_done[2] = {0, 0};
+  if (p.R) {
+    if (da_ensure_dyn_smem((const void*)gemm_nt_ws_kernel<KS, NT, true>, SMEM, &attr_done[1]) != DA_OK) return DA_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_nt_ws_kernel<KS, NT, true>), dim3(gx), dim3(256), SMEM, stream, p);
+  } else {
+    if (da_ensure_dyn_smem((const void*)gemm_nt_ws_kernel<KS, NT, false>, SMEM, &attr_done[0]) != DA_OK) return DA_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_nt_ws_kernel<KS, NT, false>), dim3(gx), dim3(256), SMEM, stream, p);
+  }
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
 }  // namespace
 
 // Called by da_gemm_nt (gemm_nt.hip) for plain bf16 linears; -1 = not eligible (the tiled form takes the call).
 int da_gemm_nt_ws_try(const void* A, long lda, const void* W, const float* bias, const void* R, long ldr, void* C, long ldc,
                       int M, int N, int K, hipStream_t stream) {
-  if (!g_nt_ws || K != WS_K || N < WS_BN || N % WS_BN || M % WS_BM) return -1;  // whole 32-row tiles only
-  const int tiles_m = M / WS_BM;
+  if (!g_nt_ws || (K != 320 && K != 640) || M % WS_BM) return -1;  // whole 32-row tiles only
+  if ((g_nt_ws & (K == 320 ? 1 : 2)) == 0) return -1;             // bit 0: the K = 320 form, bit 1: K = 640
   const int cus = da_usable_cus(256);
-  if ((long)tiles_m * (N / WS_BN) < 8L * cus) return -1;  // each workgroup loads 200 KB of W before its first 20 KB tile
   if ((lda & 7) || (ldc & 7) || (R && (ldr & 7)) || ((size_t)A & 15) || ((size_t)C & 15) || ((size_t)W & 15) || (R && ((size_t)R & 15)))
     return -1;
   if (64 * lda * 2 >= (1L << 31) || 64 * ldc * 2 >= (1L << 31) || (R && 64 * ldr * 2 >= (1L << 31))) return -1;
   GemmWsParams p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = bias; p.R = (const bf16*)R; p.C = (bf16*)C;
-  p.lda = lda; p.ldr = ldr; p.ldc = ldc; p.M = M; p.N = N; p.tiles_m = tiles_m;
-  const int nb = N / WS_BN;
-  if (nb > 4) return -1;
-  p.nb = nb;
-  const int gx = (cus / 8) * 8;  // whole rounds of the 8 XCDs (see the kernel's slot mapping)
-  if (gx < 8 * nb) return -1;
-  constexpr int SMEM = WS_NS * WS_STAGE;
-  static unsigned long long attr_done[2] = {0, 0};
-  if (R) {
-    if (da_ensure_dyn_smem((const void*)gemm_nt_ws_kernel<true>, SMEM, &attr_done[1]) != DA_OK) return DA_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_nt_ws_kernel<true>), dim3(gx), dim3(256), SMEM, stream, p);
-  } else {
-    if (da_ensure_dyn_smem((const void*)gemm_nt_ws_kernel<false>, SMEM, &attr_done[0]) != DA_OK) return DA_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_nt_ws_kernel<false>), dim3(gx), dim3(256), SMEM, stream, p);
-  }
-  DA_CHECK_LAUNCH();
-  return DA_OK;
+  p.lda = lda; p.ldr = ldr; p.ldc = ldc; p.M = M; p.N = N; p.tiles_m = M / WS_BM; p.nb = 1;
+  if (K == 320) return N <= 1280 ? launch_ws<10, 5>(p, N, cus, stream) : -1;
+  return launch_ws<20, 2>(p, N, cus, stream);
 }

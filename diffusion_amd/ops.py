@@ -159,9 +159,10 @@ def gemm_nt(A, W, out, g: Geom, *, bias=None, rowbias=None, residual=None, alpha
                 14: 'gemm_nt2_kernel<4,4,4,4>', 15: 'gemm_nt2_kernel<1,5,8,2,mf32>', 16: 'gemm_nt2_kernel<2,5,4,2,mf32>',
                 18: 'gemm_nt2_kernel<3,4,8,2>'}[v]
         # the weight-stationary form takes the K = 320 linears first (da_gemm_nt_ws_try, gemm_nt_ws.hip: same conditions)
-        if (_opt('gemm_nt_ws', 1) and _opt('gemm_nt_variant', 0) == 0 and K == 320 and N % 320 == 0 and 320 <= N <= 1280
-                and M % 32 == 0 and (M // 32) * (N // 320) >= 8 * 256 and g.ksize == 1 and g.mode == 0 and not out_fp32
-                and alpha == 1.0 and rowbias is None):
+        ws = _opt('gemm_nt_ws', 1)
+        ws_bn = 320 if (K == 320 and (ws & 1) and N <= 1280) else 128 if (K == 640 and (ws & 2) and N <= 1024) else 0
+        if (ws_bn and _opt('gemm_nt_variant', 0) == 0 and N % ws_bn == 0 and M % 32 == 0 and (M // 32) * (N // ws_bn) >= 8 * 256
+                and g.ksize == 1 and g.mode == 0 and not out_fp32 and alpha == 1.0 and rowbias is None):
             name = 'gemm_nt_ws_kernel'
     with _Timed(name, flops, (M, N, K, g.ksize, g.mode)):
         _lib.call('da_gemm_nt', a_ptr, lda, w_ptr, c_ptr, ldc, _vec(bias, N, 'bias'), rb_ptr, ldrb, r_ptr, ldr, M, N,

@@ -517,14 +517,14 @@ def test_wgrad_v2_split_workspace(ops, dev):
         ops.SPLITK_WS = old
 
 
-@pytest.mark.parametrize('M,N', [(65536, 320), (32768 + 32, 320), (32768 + 96, 960), (65536 + 64, 640), (32768 + 40, 320)])
-def test_gemm_nt_weight_stationary_form_equals_tiled_form(ops, dev, M, N):
-    """gemm_nt_ws.hip (K = 320 linears: the weight held in registers by four waves, activations streamed through LDS two tiles
-    ahead, direct epilogue; da_set_option('gemm_nt_ws', 1)) against the tiled form (0): same products, same order, same
+@pytest.mark.parametrize('M,N,K', [(65536, 320, 320), (32768 + 32, 320, 320), (32768 + 96, 960, 320), (65536 + 64, 640, 320),
+                                   (32768 + 40, 320, 320), (65536, 640, 640), (16384 + 32, 640, 640), (16384 + 64, 1024, 640)])
+def test_gemm_nt_weight_stationary_form_equals_tiled_form(ops, dev, M, N, K):
+    """gemm_nt_ws.hip (K = 320 / 640 linears: the weight held in registers by four waves, activations streamed through an LDS
+    ring, two-buffer software pipeline, direct epilogue; da_set_option('gemm_nt_ws', 3)) against the tiled form (0): same products, same order, same
     roundings -> BIT-identical, with / without bias and residual, an in-place residual, strided views, one and several
     320-column blocks, workgroups with 4 and 5 tiles (the pipeline's drain step on either accumulator set); M % 32 != 0 is
     not a shape for it (the tiled form takes the call)."""
-    K = 320
     A = rnd(M, K, dev=dev, seed=1).to(BF); W = rnd(N, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
     bias = rnd(N, dev=dev, seed=3); R = rnd(M, N, dev=dev, seed=4).to(BF)
     wide = rnd(M, N + 64, dev=dev, seed=5).to(BF); Awide = rnd(M, K + 64, dev=dev, seed=6).to(BF)
@@ -546,10 +546,10 @@ def test_gemm_nt_weight_stationary_form_equals_tiled_form(ops, dev, M, N):
     try:
         ops.set_option('gemm_nt_ws', 0)
         ref = run()
-        ops.set_option('gemm_nt_ws', 1)
+        ops.set_option('gemm_nt_ws', 3)
         got = run()
     finally:
-        ops.set_option('gemm_nt_ws', 0)
+        ops.set_option('gemm_nt_ws', 1)
     for i, (r, g_) in enumerate(zip(ref, got)):
         assert torch.equal(r, g_), f'form {i}: max |diff| {(r.float() - g_.float()).abs().max().item()}'
     full = A.float() @ W.float().t()
