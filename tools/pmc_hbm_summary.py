@@ -14,7 +14,7 @@ def short(name):
         if m.group(1) == 'gemm_nt2_kernel':
             return 'gemm_nt2<%s>' % ','.join(args[:4])
         return 'gemm_tn2<%s>' % args[0]
-    for k in ('attn_fwd', 'attn_bwd_dq', 'attn_bwd_dkv', 'attn_bwd_fused', 'adamw', 'geglu_bwd', 'geglu_fwd'):
+    for k in ('attn_fwd', 'attn_bwd_dq', 'attn_bwd_dkv', 'attn_bwd_fused', 'adamw', 'geglu_bwd', 'geglu_fwd', 'gemm_nt_ws'):
         if k in name:
             return k
     return None
