@@ -17,8 +17,8 @@
 // K = 640 (WsCfg<20, 2>, opt-in: bit 1 of the option): a workgroup holds W for 128 output columns (160 KB; wave w columns
 // 32w .. 32w+31 over all of K), the stages are 32 rows x 1280 B (40 KB, ring of four = the whole LDS, chunk XOR row & 15),
 // N = 640 is five column blocks whose workgroups share an XCD and read the activation rows through its L2.  Bit-identical
-// too, but not faster: 65536 x 640 x 640 61 us against 56 us tiled (each of its 43 tiles per workgroup costs 10 tile requests
-// and a barrier for 80 MFMAs per wave), 262144 x 640 x 640 236 against 245.
+// too; 65536 x 640 x 640 54 us against 57 us tiled in isolation (each of its 43 tiles per workgroup costs 10 tile requests
+// and a barrier for 80 MFMAs per wave), the step -0.2 %: not switched on.
 #include <type_traits>
 #include "common.hpp"
 #include "diffusion_amd.h"
@@ -56,6 +56,15 @@ struct WsCfg {
   // number of 128-byte halves (640 B) need three bits, (row >> 1) & 7; rows of whole 256-byte bank rows (1280 B) four, row & 15
   static constexpr int SWB = (ROWB % 256 == 0) ? 4 : 3;
   static constexpr int PER = 1 << (SWB - 2);       // fragment base registers per lane (K-steps s, s + PER, ... share one)
+  // SPREAD: the PD requests of a step go out one per K-step, unconditionally (past the end the last tile is requested again:
+  // an L2 hit into a stage nobody reads - no branch in the product stream, constant counts), instead of one block in front
+  // of the products.  Measured: K = 640 (10 requests per 80 MFMAs) 61.8 -> 54.3 us at 65536 x 640 x 640; K = 320 (5 per 100)
+  // +-1 %; the same behind a uniform branch per piece -7...-13 %.
+#ifdef WS_SPREAD
+  static constexpr bool SPREAD = WS_SPREAD != 0;
+#else
+  static constexpr bool SPREAD = KS >= 20;
+#endif
   static_assert(STAGE % 4096 == 0 && WS_NS * STAGE <= 160 * 1024 && (ROWB / 16) % (1 << SWB) % 8 == 0, "stage geometry");
 };
 
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
     int n = j0 >= 1 ? G::PO : 0;
 #pragma unroll
     for (int d = 1; d < WS_AHEAD; ++d)
-      n += (HASR ? G::PO : 0) + (j0 + d + WS_AHEAD < n_my ? G::PD : 0) + G::PO;
+      n += (HASR ? G::PO : 0) + ((G::SPREAD || j0 + d + WS_AHEAD < n_my) ? G::PD : 0) + G::PO;
     return n < 60 ? n : 60;  // the counter has 6 bits; leaving fewer in flight than allowed is always safe
   };
 
@@ -252,10 +261,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
 #pragma unroll
       for (int q = 0; q < G::PO; ++q) rin[q] = ws_load16(rb, out_off(q, p.ldr));
     }
-    // (the PD requests in one block: spread one per K-step over the products - each behind its own uniform branch - the
-    // step measured 7-13 % slower)
-    bool requested = false;
-    if constexpr (C) {
+    // the PD requests of tile k + WS_AHEAD: one block here, or (G::SPREAD) one per K-step below
+    bool requested = C && G::SPREAD;
+    const int kreq = min(k + WS_AHEAD, n_my - 1);
+    const char* req_base = reinterpret_cast<const char*>(p.A) + (long)(slot + kreq * grid) * WS_BM * p.lda * 2;
+    char* req_dst = smem + ((k + WS_AHEAD) % WS_NS) * G::STAGE + wave * (G::PD * 1024);
+    static_assert(G::PD <= KS - G::PO, "requests before the first output piece");
+    if constexpr (C && !G::SPREAD) {
       if (k + WS_AHEAD < n_my) {
         WS_REQ(k + WS_AHEAD);
         requested = true;
@@ -307,6 +319,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
                        : "s"(__builtin_amdgcn_readfirstlane((int)requested)), "n"(G::PD)
                        : "scc", "memory");
       }
+      if constexpr (C && G::SPREAD && s < G::PD) glds16_ws(req_base + dsrc[s], req_dst + s * 1024);
       if constexpr (C) {
         if constexpr (s + 1 < KS) {
           constexpr int OFF = 64 * G::PER * ((s + 1) / G::PER);
