@@ -1111,6 +1111,9 @@ int da_gemm_nt_v2_dispatch(int variant, int splits, float* ws, const void* A, lo
   return variant == 5 ? launch_v2<4, 5, 4, 2, 64>(p, splits, ws, stream) : launch_v2<4, 4, 4, 2, 64>(p, splits, ws, stream);
 }
 
+int da_gemm_nt_geglu_ws_try(const void* A, long lda, const void* W, const float* bias, void* F, long ldf, void* G, long ldg,
+                            int M, int inner, int K, hipStream_t stream);  // gemm_nt_ws.hip: -1 = not a shape for it
+
 /* F[M][2*inner] = A[M][K] . W[2*inner][K]^T + bias ; G[M][inner] = F[:, :inner] * gelu(F[:, inner:]) in one launch */
 extern "C" int da_gemm_nt_geglu(const void* A, long lda, const void* W, void* F, long ldf, void* G, long ldg,
                                 const float* bias, int M, int inner, int K, hipStream_t stream) {
@@ -1118,6 +1121,10 @@ extern "C" int da_gemm_nt_geglu(const void* A, long lda, const void* W, void* F,
   if (M <= 0 || inner <= 0 || K <= 0) return DA_ERR_SHAPE;
   if ((inner % 160) || (K % 64) || (lda & 7) || (ldf & 7) || (ldg & 7)) return DA_ERR_SHAPE;
   if ((long)M * lda * 2 >= (1L << 32) || (long)inner * K * 4 >= (1L << 32)) return DA_ERR_SHAPE;  // 32-bit byte offsets of the DMA sources
+  {
+    const int rc = da_gemm_nt_geglu_ws_try(A, lda, W, bias, F, ldf, G, ldg, M, inner, K, stream);  // weight-stationary form (K = 320)
+    if (rc >= 0) return rc;
+  }
   GemmNT2Params p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = F; p.bias = bias;
   p.rowbias = nullptr; p.R = nullptr;

@@ -24,7 +24,7 @@
 #include "diffusion_amd.h"
 
 int da_usable_cus(int cus);  // gemm_nt_v2.hip
-int g_nt_ws = 1;             // da_set_option("gemm_nt_ws", bits): 1 = the K = 320 form (on), 2 = the K = 640 form (off: measured slower)
+int g_nt_ws = 1;             // da_set_option("gemm_nt_ws", bits): 1 = the K = 320 linears (on), 2 = K = 640 (off), 4 = the fused GEGLU forward at K = 320
 
 namespace {
 
@@ -36,6 +36,9 @@ struct GemmWsParams {
   bf16* C;
   long lda, ldr, ldc;
   int M, N, tiles_m, nb;
+  bf16* G;      // MODE 1 (fused GEGLU forward): C = F[M][2*inner] (pre-activation), G[M][inner] = F[:, :inner] * gelu(F[:, inner:])
+  long ldg;
+  int inner;
 };
 
 constexpr int WS_BM = 32;  // rows per tile: two 16-row MFMA strips
@@ -46,12 +49,16 @@ constexpr int WS_NS = WS_NS_BUILD;   // LDS stages (ring); 4 / 6 / 8 measured eq
 constexpr int WS_AHEAD = WS_NS - 1;  // tiles requested ahead of the one being computed
 
 // KS = K / 32 MFMA K-steps, NT = 16-column MFMA tiles per wave
-template <int KS, int NT>
+// MODE 1 = fused GEGLU forward: a wave's NT column tiles are NT/2 tiles of VALUE columns and the NT/2 tiles of the GATE columns of the
+// same hidden units (so the gating is lane-local); BN then counts hidden units per workgroup
+template <int KS, int NT, int MODE = 0>
 struct WsCfg {
-  static constexpr int K = 32 * KS, BN = 64 * NT, ROWB = 64 * KS, STAGE = WS_BM * ROWB;
+  static constexpr int K = 32 * KS, BN = MODE == 1 ? 32 * NT : 64 * NT, ROWB = 64 * KS, STAGE = WS_BM * ROWB;
   static constexpr int PD = STAGE / 4096;          // LDS-DMA instructions per wave and tile
   static constexpr int NPJ = NT / 2, ODD = NT & 1;  // column-tile pairs per strip; a last tile paired across the two strips
-  static constexpr int PO = 2 * NPJ + ODD;         // 16-byte output pieces per lane and tile (= residual loads = stores)
+  // 16-byte output pieces per lane and tile (= residual loads = stores); MODE 1: per strip F value, F gate and G, NT/4 pairs each
+  static constexpr int PO = MODE == 1 ? 6 * (NT / 4) : 2 * NPJ + ODD;
+  static_assert(MODE == 0 || NT == 4, "GEGLU form: two value + two gate tiles per wave");
   // source-side XOR of the 16-byte chunk index that makes ds_read_b128 of 16 consecutive rows conflict-free: rows of an odd
   // number of 128-byte halves (640 B) need three bits, (row >> 1) & 7; rows of whole 256-byte bank rows (1280 B) four, row & 15
   static constexpr int SWB = (ROWB % 256 == 0) ? 4 : 3;
@@ -108,9 +115,10 @@ DEVINL void ws_wait_vm(int n) {  // all but the n youngest vector-memory operati
   }
 }
 
-template <int KS, int NT, bool HASR>
+template <int KS, int NT, bool HASR, int MODE = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
-  typedef WsCfg<KS, NT> G;
+  typedef WsCfg<KS, NT, MODE> G;
+  static_assert(MODE == 0 || !HASR, "no residual in the GEGLU form");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // WS_NS stages of 32 activation rows
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
   typedef float accv_t __attribute__((ext_vector_type(4)));
@@ -177,20 +185,24 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
   for (int k = 0; k < WS_AHEAD; ++k)
     if (k < n_my) WS_REQ(k);
   // ---- the resident weight fragments: W rows n0 + 16*NT*wave + 16*jt + (lane & 15), k = 32*s + 8*(lane >> 4) .. + 7
+  // (MODE 1: n0 is the workgroup's first hidden unit; tiles jt < NT/2 are its value rows of W, the others the gate rows)
+  auto wcol = [&](int jt) {  // first output column (= row of W) of this wave's tile jt
+    if constexpr (MODE == 1) return (jt < NT / 2 ? 0 : p.inner) + n0 + 8 * NT * wave + 16 * (jt % (NT / 2));
+    else return n0 + 16 * NT * wave + 16 * jt;
+  };
   bf16x8 wf[NT][KS];
-  {
-    const bf16* wp = p.W + (long)(n0 + 16 * NT * wave + l15) * G::K + 8 * g4;
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
+  for (int jt = 0; jt < NT; ++jt) {
+    const bf16* wp = p.W + (long)(wcol(jt) + l15) * G::K + 8 * g4;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) wf[jt][s] = ld8(wp + (long)(16 * jt) * G::K + 32 * s);
+    for (int s = 0; s < KS; ++s) wf[jt][s] = ld8(wp + 32 * s);
   }
   // bias of this lane's accumulator columns n0 + 16*NT*wave + 16*jt + 4*(lane >> 4) + e: the start value of every K sum
   accv_t bv[NT];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bv[jt][e] = p.bias ? p.bias[n0 + 16 * NT * wave + 16 * jt + 4 * g4 + e] : 0.f;
+    for (int e = 0; e < 4; ++e) bv[jt][e] = p.bias ? p.bias[wcol(jt) + 4 * g4 + e] : 0.f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the counted waits below start from zero
   // ... and the compiler's own bookkeeping too: redefined here, the fragments are no pending loads to it (it would otherwise
   // wait vmcnt(0) for them in front of the first product - behind the tile requests in flight)
@@ -204,8 +216,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
   // ---- this lane's 16 bytes of the output tile (the direct epilogue of gemm_nt_v2.hip with wm = 0, MT = 2, wn = wave):
   // pieces q = (strip i, column pair pj): q < NPJ -> (0, q), q < 2*NPJ -> (1, q - NPJ), q = 2*NPJ (NT odd) -> the last column
   // tile of both strips
-  const int lq = g4 & 1, lcol = 16 * NT * wave + 8 * (lane >> 5);
+  const int lq = g4 & 1, lcol = (MODE == 1 ? 8 : 16) * NT * wave + 8 * (lane >> 5);
   auto out_off = [&](int q, long ld) {
+    if constexpr (MODE == 1) {  // q = 3*i + kind (F value, F gate, G): the value-tile pair's position; kind 1 adds inner columns
+      const int row = l15 + 16 * (q / 3), col = lcol + 16 * lq + ((q % 3) == 1 ? p.inner : 0);
+      return (unsigned)row * (unsigned)(ld * 2) + (unsigned)(n0 + col) * 2u;
+    }
     const bool odd = q >= 2 * G::NPJ;
     const int i = q < G::NPJ ? 0 : 1, pj = q < G::NPJ ? q : q - G::NPJ;
     const int row = odd ? l15 + 16 * lq : l15 + 16 * i;
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
     const int kreq = min(k + WS_AHEAD, n_my - 1);
     const char* req_base = reinterpret_cast<const char*>(p.A) + (long)(slot + kreq * grid) * WS_BM * p.lda * 2;
     char* req_dst = smem + ((k + WS_AHEAD) % WS_NS) * G::STAGE + wave * (G::PD * 1024);
-    static_assert(G::PD <= KS - G::PO, "requests before the first output piece");
+    static_assert(!G::SPREAD || G::PD <= KS - G::PO, "spread requests go out before the first output piece");
     if constexpr (C && !G::SPREAD) {
       if (k + WS_AHEAD < n_my) {
         WS_REQ(k + WS_AHEAD);
@@ -278,13 +294,30 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
     for (int m = 0; m < G::PER; ++m) fbase[m] = smem_off + (unsigned)(st * G::STAGE) + frag_off + (unsigned)((m ^ (fsw >> 2)) << 6);
     char* cb = reinterpret_cast<char*>(p.C) + (long)(slot + (k - 1) * grid) * WS_BM * p.ldc * 2;
     auto piece = [&](int q) {  // the finished tile's 16-byte pieces in strip order
-      const bool odd = q >= 2 * G::NPJ;
-      const int i = q < G::NPJ ? 0 : 1, pj = q < G::NPJ ? q : q - G::NPJ;
-      const u32x4 o = odd ? finish(prev[0][NT - 1], prev[1][NT - 1], rin[q]) : finish(prev[i][2 * pj], prev[i][2 * pj + 1], rin[q]);
+      u32x4 o;
+      char* dst = cb + out_off(q, p.ldc);
+      if constexpr (MODE == 1) {
+        // value and gate rounded to bf16 BEFORE gating, exactly as the tiled fused form (gemm_nt_v2.hip, GEGLU == 1)
+        const int i = q / 3, kind = q % 3;
+        accv_t x[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float fv = bf2f(f2bf(prev[i][t][e])), fg = bf2f(f2bf(prev[i][2 + t][e]));
+            x[t][e] = kind == 0 ? fv : kind == 1 ? fg : fv * gelu_f(fg);
+          }
+        o = finish(x[0], x[1], rin[q]);
+        if (kind == 2) dst = reinterpret_cast<char*>(p.G) + (long)(slot + (k - 1) * grid) * WS_BM * p.ldg * 2 + out_off(q, p.ldg);
+      } else {
+        const bool odd = q >= 2 * G::NPJ;
+        const int i = q < G::NPJ ? 0 : 1, pj = q < G::NPJ ? q : q - G::NPJ;
+        o = odd ? finish(prev[0][NT - 1], prev[1][NT - 1], rin[q]) : finish(prev[i][2 * pj], prev[i][2 * pj + 1], rin[q]);
+      }
 #ifdef WS_EXP_NOSTORE   // timing-only build (tools/build_alt.sh): everything but the stores
-      asm volatile("" ::"v"(o));
+      asm volatile("" ::"v"(o), "v"(dst));
 #else
-      *reinterpret_cast<u32x4*>(cb + out_off(q, p.ldc)) = o;
+      *reinterpret_cast<u32x4*>(dst) = o;
 #endif
     };
     bf16x8 a_cur[2], a_nxt[2];
@@ -397,6 +430,29 @@ int da_gemm_nt_ws_try(const void* A, long lda, const void* W, const float* bias,
   GemmWsParams p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = bias; p.R = (const bf16*)R; p.C = (bf16*)C;
   p.lda = lda; p.ldr = ldr; p.ldc = ldc; p.M = M; p.N = N; p.tiles_m = M / WS_BM; p.nb = 1;
+  p.G = nullptr; p.ldg = 0; p.inner = 0;
   if (K == 320) return N <= 1280 ? launch_ws<10, 5>(p, N, cus, stream) : -1;
   return launch_ws<20, 2>(p, N, cus, stream);
+}
+
+// Called by da_gemm_nt_geglu (gemm_nt_v2.hip); -1 = not eligible.  K = 320 only: 128 hidden units per workgroup (each wave
+// 32 value + the 32 matching gate columns over all of K = 160 registers), inner / 128 column blocks per row walk on one XCD.
+int da_gemm_nt_geglu_ws_try(const void* A, long lda, const void* W, const float* bias, void* F, long ldf, void* G, long ldg,
+                            int M, int inner, int K, hipStream_t stream) {
+  typedef WsCfg<10, 4, 1> Gc;
+  if (!(g_nt_ws & 4) || K != Gc::K || M % WS_BM || inner % Gc::BN) return -1;
+  const int nb = inner / Gc::BN, cus = da_usable_cus(256), gx = (cus / 8) * 8;
+  if (nb < 1 || gx / 8 < nb || (long)(M / WS_BM) * nb < 8L * cus) return -1;
+  if ((lda & 7) || (ldf & 7) || (ldg & 7) || ((size_t)A & 15) || ((size_t)F & 15) || ((size_t)G & 15) || ((size_t)W & 15)) return -1;
+  if (64 * lda * 2 >= (1L << 31) || 64 * ldf * 2 >= (1L << 31) || 64 * ldg * 2 >= (1L << 31)) return -1;
+  GemmWsParams p;
+  p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = bias; p.R = nullptr; p.C = (bf16*)F;
+  p.lda = lda; p.ldr = 0; p.ldc = ldf; p.M = M; p.N = 2 * inner; p.tiles_m = M / WS_BM; p.nb = nb;
+  p.G = (bf16*)G; p.ldg = ldg; p.inner = inner;
+  constexpr int SMEM = WS_NS * Gc::STAGE;
+  static unsigned long long attr_done = 0;
+  if (da_ensure_dyn_smem((const void*)gemm_nt_ws_kernel<10, 4, false, 1>, SMEM, &attr_done) != DA_OK) return DA_ERR_LAUNCH;
+  hipLaunchKernelGGL((gemm_nt_ws_kernel<10, 4, false, 1>), dim3(gx), dim3(256), SMEM, stream, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
 }

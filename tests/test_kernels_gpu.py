@@ -558,6 +558,38 @@ def test_gemm_nt_weight_stationary_form_equals_tiled_form(ops, dev, M, N, K):
     assert (got[5][:, :32] == 0).all() and (got[5][:, 32 + N:] == 0).all()
 
 
+@pytest.mark.parametrize('M', [8192 + 32, 32768])
+def test_geglu_weight_stationary_form_equals_tiled_form(ops, dev, M):
+    """The fused GEGLU forward at K = 320 in the weight-stationary kernel (gemm_nt_ws.hip MODE 1: each wave holds 32 value columns
+    and the 32 matching gate columns of W, gating is lane-local; bit 2 of da_set_option('gemm_nt_ws')) against the tiled fused
+    form: F (pre-activation) and G (gated) BIT-identical, strided outputs, and both against fp32 PyTorch."""
+    K, inner = 320, 1280
+    A = rnd(M, K, dev=dev, seed=1).to(BF); W = rnd(2 * inner, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
+    bias = rnd(2 * inner, dev=dev, seed=3)
+
+    def run():
+        F = torch.full((M, 2 * inner), 7.0, device=dev, dtype=BF); G = torch.full((M, inner), 7.0, device=dev, dtype=BF)
+        ops.gemm_nt_geglu(A, W, F, G, bias)
+        Fw = torch.zeros(M, 2 * inner + 64, device=dev, dtype=BF); Gw = torch.zeros(M, inner + 64, device=dev, dtype=BF)
+        ops.gemm_nt_geglu(A, W, Fw[:, 32:32 + 2 * inner], Gw[:, 16:16 + inner], bias)
+        return F, G, Fw, Gw
+
+    try:
+        ops.set_option('gemm_nt_ws', 1)
+        ref = run()
+        ops.set_option('gemm_nt_ws', 5)
+        got = run()
+    finally:
+        ops.set_option('gemm_nt_ws', 1)
+    for i, (r, g_) in enumerate(zip(ref, got)):
+        assert torch.equal(r, g_), f'output {i}: max |diff| {(r.float() - g_.float()).abs().max().item()}'
+    f = A.float() @ W.float().t() + bias
+    check(got[0], f, what='ws geglu F')
+    fb = got[0].float()
+    check(got[1], fb[:, :inner] * torch.nn.functional.gelu(fb[:, inner:]), what='ws geglu G')
+    assert (got[2][:, :32] == 0).all() and (got[3][:, 16 + inner:] == 0).all()
+
+
 @pytest.mark.parametrize('ring', [4, 5])
 @pytest.mark.parametrize('M,N,K', [(16384, 1280, 1280), (65536, 320, 320), (8192, 328, 200), (4096, 10240, 1536), (1024, 320, 640), (2048, 64, 64)])
 def test_wgrad_ring_form_equals_two_stage_form(ops, dev, ring, M, N, K):
