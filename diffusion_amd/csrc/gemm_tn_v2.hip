@@ -42,6 +42,7 @@ struct GemmTN2Params {
   float* bslab;  // the bias-gradient partials of the same splits, [tn][split][320] fp32 (behind the tile slabs)
   int overwrite;  // da_set_option("grad_overwrite"): dW / dbias are written, not added to
   int period;  // FAST path: the border pattern of a lane's X rows repeats every `period` 64-pixel steps
+  int ups64;   // FAST path, fused upsample with Wout == 64: a step is ONE output row, the source row advances every second step
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page_tn[256];
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
 
   int mcur_f = m_begin;
   // ---- FAST-path descriptors (see the template comment); the generic ones follow
-  unsigned fa_off[T2_AJ], fx_off[T2_BJ], fx_m0[T2_BJ], fx_m1[T2_BJ];
+  unsigned fa_off[T2_AJ], fx_off[T2_BJ], fx_off1[T2_BJ], fx_m0[T2_BJ], fx_m1[T2_BJ];
   // source pixels per 64-pixel step and the (uniform) source element offset of step 0's first image row block
   const int src_step = (int)((long)T2_MS * p.Hin * p.Win / HWo);
   // the uniform base sits pad*(Win+1) source pixels below the block's first one, so every lane offset is >= 0
@@ -156,6 +157,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
         // signed, NOT clamped (the slot is valid again at later steps and must keep a linear offset); >> floors
         const int ih = (oh * gmul + r - pad) >> gshift, iw = (ow * gmul + s2 - pad) >> gshift;
         fx_off[j] = (unsigned)(((long)bb * p.Hin * p.Win + (long)ih * p.Win + iw) * p.ldx + c - x_base0);
+        fx_off1[j] = fx_off[j];
+        if (p.ups64) {
+          // one output row per step: source row (oh + r - 1) >> 1 = (oh >> 1) + cpar with cpar = (b + r - 1) >> 1 for the row's
+          // parity b - two lane offsets relative to the uniform base (oh >> 1) * Win - margin, selected by the step's parity
+          fx_off[j] = (unsigned)((long)((((0 + r - 1) >> 1) + 1) * p.Win + iw + 1) * p.ldx + c);
+          fx_off1[j] = (unsigned)((long)((((1 + r - 1) >> 1) + 1) * p.Win + iw + 1) * p.ldx + c);
+        }
       }
       if (kok) {
         if (p.ksize == 1 && p.mode == 0) {
@@ -185,13 +193,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(GemmTN2Params p) {
     const bf16* ab = p.dY + (long)mc * p.lddy;
 #pragma unroll
     for (int j = 0; j < T2_AJ; ++j) glds16_tn(ab + fa_off[j], Ab + (wave * T2_AJ + j) * 1024);
-    const bf16* xb = p.X + ((long)(mc / T2_MS) * src_step - x_margin) * p.ldx;
+    const int grow = mc / T2_MS;  // ups64: the global output row of this step
+    const bf16* xb = p.X + ((p.ups64 ? (long)(grow >> 1) * p.Win : (long)grow * src_step) - x_margin) * p.ldx;
+    const bool odd_row = p.ups64 && (grow & 1);
     const unsigned pb0 = (live && phase < 32) ? (1u << phase) : 0u;
     const unsigned pb1 = (live && phase >= 32) ? (1u << (phase - 32)) : 0u;
 #pragma unroll
     for (int j = 0; j < T2_BJ; ++j) {
       const bool ok = ((fx_m0[j] & pb0) | (fx_m1[j] & pb1)) != 0;
-      const void* src = ok ? (const void*)(xb + fx_off[j]) : (const void*)zero;
+      const void* src = ok ? (const void*)(xb + (odd_row ? fx_off1[j] : fx_off[j])) : (const void*)zero;
       glds16_tn(src, Bb + (wave * T2_BJ + j) * 1024);
     }
     mcur_f += T2_MS;
@@ -658,7 +668,8 @@ int launch_tn2(GemmTN2Params p, float* ws, long ws_floats, hipStream_t stream) {
 // in steps (0: not eligible, the generic gather runs).
 int da_gemm_tn_v2_fast_period(int M, int N, int Hin, int Win, int Hout, int Wout, int mode) {
   const int HWo = Hout * Wout;
-  const bool rows_ok = mode == 0 || (mode == 1 && T2_MS % Wout == 0) || (mode == 3 && T2_MS % (2 * Wout) == 0);
+  const bool rows_ok = mode == 0 || (mode == 1 && T2_MS % Wout == 0) || (mode == 3 && T2_MS % (2 * Wout) == 0) ||
+                       (mode == 3 && Wout == T2_MS && Hout % 2 == 0 && 2 * Hin == Hout && 2 * Win == Wout);  // ups64
   if (rows_ok && M % T2_MS == 0 && N >= 8 && ((long)T2_MS * Hin * Win) % HWo == 0) {
     if (HWo % T2_MS == 0 && HWo / T2_MS <= 64) return HWo / T2_MS;
     if (T2_MS % HWo == 0) return 1;
@@ -683,5 +694,6 @@ int da_gemm_tn_v2_dispatch(int variant, const void* dY, long lddy, const void* X
   p.overwrite = 0;
   (void)variant;  // the 320x256 instantiation (160 accumulators) spills on gfx950 and lost to 320x192 everywhere
   p.period = da_gemm_tn_v2_fast_period(M, N, Hin, Win, Hout, Wout, mode);
+  p.ups64 = (p.period && mode == 3 && Wout == T2_MS) ? 1 : 0;
   return p.period ? launch_tn2<192, true>(p, ws, ws_floats, stream) : launch_tn2<192, false>(p, ws, ws_floats, stream);
 }
