@@ -70,6 +70,16 @@ int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* 
  *                       n > 0 that many resident workgroups | 0 one workgroup per tile
  *   "gemm_nt_persist_conv" 1 (default) 3x3 convolutions with more tiles than CUs also run as a resident tile walk (next tile's
  *                       descriptors + first K-step ahead of the epilogue; +0...1.4 %, bit-identical) | 0 one workgroup per tile
+ *   "gemm_nt_de"        1 (default) the convolution forms leave through the direct register -> HBM epilogue | 0 the LDS strip
+ *                       epilogue everywhere | 2 / 3 also the linears without / with a residual (measured slower).  Bit-identical.
+ *   "gemm_nt_ws"        bit mask, default 1: bit 0 the K = 320 linears (N = 320 ... 1280, M % 32 == 0, >= 8 row tiles per CU) run in
+ *                       the weight-stationary kernel (W in the registers of four waves; gemm_nt_ws.hip) | bit 1 the K = 640 linears
+ *                       too | bit 2 the fused GEGLU forward at K = 320 too (both measured +-0 in the step).  Bit-identical.
+ *   "gemm_nt_stream"    0 (default) | 1 / 2 the streaming short-K linear kernel (gemm_nt_v3.hip; slower) where it measured best /
+ *                       wherever eligible; "gemm_nt_stream_lw" 4 | 16 its loader waves.  Bit-identical.
+ *   "gemm_tn_ring"      0 (default) | 4 | 5: linear-layer weight gradients with a ring of 32-pixel half-stages (+-3 %).  Bit-identical.
+ *   "attn_fused_bwd"    1 (default) da_attn_bwd runs as ONE kernel for Nk <= 128 (cross-attention, the 64-token level) | 0 the
+ *                       dK/dV + dQ pair | 2 also 129 ... 256 keys on an 8-wave form (slower)
  *   "gemm_tn_variant"   0 auto | 1 the 128x128x32 wgrad kernel | 2 the 320x192x64 LDS-DMA wgrad kernel
  *   "gn_resident"       n (default 192): da_groupnorm_fwd / _bwd run as ONE kernel that holds a workgroup's (image, whole groups)
  *                       slab in registers - x (and dy) are read once - when the slab fits and the launch has >= n workgroups;
