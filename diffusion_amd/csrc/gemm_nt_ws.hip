@@ -394,6 +394,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#undef WS_REQ
+
 template <int KS, int NT>
 int launch_ws(GemmWsParams p, int N, int cus, hipStream_t stream) {
   typedef WsCfg<KS, NT> G;
