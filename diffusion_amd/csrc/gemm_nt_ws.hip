@@ -24,7 +24,7 @@
 #include "diffusion_amd.h"
 
 int da_usable_cus(int cus);  // gemm_nt_v2.hip
-int g_nt_ws = 1;             // da_set_option("gemm_nt_ws", bits): 1 = the K = 320 linears (on), 2 = K = 640 (off), 4 = the fused GEGLU forward at K = 320
+int g_nt_ws = 1;             // da_set_option("gemm_nt_ws", bits): 1 = the K = 320 linears (on), 2 = K = 640 (off), 4 = the fused GEGLU forward at K = 320, 8 = K = 640 as two unpipelined workgroups per CU
 
 namespace {
 
@@ -115,11 +115,14 @@ DEVINL void ws_wait_vm(int n) {  // all but the n youngest vector-memory operati
   }
 }
 
-template <int KS, int NT, bool HASR, int MODE = 0>
-__global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
+// PIPE = false: no software pipeline and ONE accumulator set - the kernel then fits 256 registers and runs as TWO workgroups per
+// CU (two waves per SIMD fill each other's gaps), with two LDS stages each (one tile ahead).
+template <int KS, int NT, bool HASR, int MODE = 0, bool PIPE = true>
+__global__ __launch_bounds__(256, PIPE ? 1 : 2) void gemm_nt_ws_kernel(GemmWsParams p) {
   typedef WsCfg<KS, NT, MODE> G;
+  constexpr int NS = PIPE ? WS_NS : 2, AHEAD = NS - 1;  // LDS stages of this form; tiles requested ahead
   static_assert(MODE == 0 || !HASR, "no residual in the GEGLU form");
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // WS_NS stages of 32 activation rows
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NS stages of 32 activation rows
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
   typedef float accv_t __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63;
@@ -148,9 +151,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
     const int swz = G::SWB == 3 ? (row >> 1) & 7 : row & 15;
     dsrc[j] = (unsigned)row * (unsigned)(p.lda * 2) + (unsigned)((pc ^ swz) << 4);
   }
-  auto request = [&](int k) {  // k-th tile of this workgroup -> stage k % WS_NS
+  auto request = [&](int k) {  // k-th tile of this workgroup -> stage k % NS
     const char* base = reinterpret_cast<const char*>(p.A) + (long)(slot + k * grid) * WS_BM * p.lda * 2;
-    char* dst = smem + (k % WS_NS) * G::STAGE + wave * (G::PD * 1024);
+    char* dst = smem + (k % NS) * G::STAGE + wave * (G::PD * 1024);
 #pragma unroll
     for (int j = 0; j < G::PD; ++j) glds16_ws(base + dsrc[j], dst + j * 1024);
   };
@@ -158,31 +161,32 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
 #define WS_REQ(k) request_hot(k)
   auto request_hot = [&](int k) {
     const char* base = reinterpret_cast<const char*>(p.A) + (long)slot * WS_BM * p.lda * 2;
-    char* dst = smem + (k % WS_NS) * G::STAGE + wave * (G::PD * 1024);
+    char* dst = smem + (k % NS) * G::STAGE + wave * (G::PD * 1024);
 #pragma unroll
     for (int j = 0; j < G::PD; ++j) glds16_ws(base + dsrc[j], dst + j * 1024);
   };
 #else
 #define WS_REQ(k) request(k)
 #endif
-  // Vector-memory operations this wave issues AFTER the requests of its tile k (k >= WS_AHEAD; issued in step k - WS_AHEAD):
+  // Vector-memory operations this wave issues AFTER the requests of its tile k (k >= AHEAD; issued in step k - AHEAD):
   // what the wait in front of tile k may leave in flight.  A step j issues, in this order: the PO residual loads of tile j - 1
-  // (j >= 1, HASR), the PD requests of tile j + WS_AHEAD (while there is one), the PO stores of tile j - 1 (j >= 1).
+  // (j >= 1, HASR), the PD requests of tile j + AHEAD (while there is one), the PO stores of tile j - 1 (j >= 1).
   // (A pure function of k on purpose: running counters captured by the step lambda ended up in scratch memory, and every
   // scratch load comes with s_waitcnt vmcnt(0).)
   auto after_requests_of = [&](int k) {
-    const int j0 = k - WS_AHEAD;
+    if constexpr (!PIPE) return (int)G::PO;  // the requests of tile k go out in the compute part of step k - 1: only its stores follow
+    const int j0 = k - AHEAD;
     int n = j0 >= 1 ? G::PO : 0;
 #pragma unroll
-    for (int d = 1; d < WS_AHEAD; ++d)
-      n += (HASR ? G::PO : 0) + ((G::SPREAD || j0 + d + WS_AHEAD < n_my) ? G::PD : 0) + G::PO;
+    for (int d = 1; d < AHEAD; ++d)
+      n += (HASR ? G::PO : 0) + ((G::SPREAD || j0 + d + AHEAD < n_my) ? G::PD : 0) + G::PO;
     return n < 60 ? n : 60;  // the counter has 6 bits; leaving fewer in flight than allowed is always safe
   };
 
   // the first tiles are requested BEFORE the 160-200 KB of weight fragments (every workgroup fetches them at once - a few
   // microseconds during which HBM would otherwise idle), then everything is waited for together
 #pragma unroll
-  for (int k = 0; k < WS_AHEAD; ++k)
+  for (int k = 0; k < AHEAD; ++k)
     if (k < n_my) WS_REQ(k);
   // ---- the resident weight fragments: W rows n0 + 16*NT*wave + 16*jt + (lane & 15), k = 32*s + 8*(lane >> 4) .. + 7
   // (MODE 1: n0 is the workgroup's first hidden unit; tiles jt < NT/2 are its value rows of W, the others the gate rows)
@@ -263,29 +267,31 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
   // single wave per SIMD has nobody else to fill the gaps between its MFMAs, so the conversion, shuffle and store
   // instructions of the finished tile are placed between the products of the next one (the last PO K-steps; the residual of
   // the finished tile is requested at the start of the step and waited for in front of the first piece).
+  u32x4 rin[G::PO];        // residual of the tile whose epilogue comes next
+  bool requested = false;  // ... and whether tile requests were issued after its loads (they are the younger operations)
   auto step = [&](acc_t& cur, acc_t& prev, auto do_compute, auto do_epi, const int k) {
     constexpr bool C = decltype(do_compute)::value, E = decltype(do_epi)::value;
-    const int st = k % WS_NS;
+    const int st = k % NS;
     if constexpr (C) {
-      if (k >= WS_AHEAD) ws_wait_vm(after_requests_of(k));  // (the first WS_AHEAD tiles landed behind the weight fragments)
+      if (k >= AHEAD) ws_wait_vm(after_requests_of(k));  // (the first AHEAD tiles landed behind the weight fragments)
       __builtin_amdgcn_s_barrier();  // everybody's pieces of tile k are in LDS; everybody is done with the stage requested next
       asm volatile("" ::: "memory");
     }
-    u32x4 rin[G::PO];
-    if constexpr (E && HASR) {
-      const char* rb = reinterpret_cast<const char*>(p.R) + (long)(slot + (k - 1) * grid) * WS_BM * p.ldr * 2;
+    // PIPE: the residual of tile k - 1 (its epilogue runs in this step); otherwise of tile k, ahead of its own products
+    if constexpr (HASR && (PIPE ? E : C)) {
+      const char* rb = reinterpret_cast<const char*>(p.R) + (long)(slot + (PIPE ? k - 1 : k) * grid) * WS_BM * p.ldr * 2;
 #pragma unroll
       for (int q = 0; q < G::PO; ++q) rin[q] = ws_load16(rb, out_off(q, p.ldr));
     }
-    // the PD requests of tile k + WS_AHEAD: one block here, or (G::SPREAD) one per K-step below
-    bool requested = C && G::SPREAD;
-    const int kreq = min(k + WS_AHEAD, n_my - 1);
+    // the PD requests of tile k + AHEAD: one block here, or (G::SPREAD) one per K-step below
+    if constexpr (C || PIPE) requested = C && G::SPREAD;  // (an epilogue-only step of the unpipelined form keeps the compute part's)
+    const int kreq = min(k + AHEAD, n_my - 1);
     const char* req_base = reinterpret_cast<const char*>(p.A) + (long)(slot + kreq * grid) * WS_BM * p.lda * 2;
-    char* req_dst = smem + ((k + WS_AHEAD) % WS_NS) * G::STAGE + wave * (G::PD * 1024);
+    char* req_dst = smem + ((k + AHEAD) % NS) * G::STAGE + wave * (G::PD * 1024);
     static_assert(!G::SPREAD || G::PD <= KS - G::PO, "spread requests go out before the first output piece");
     if constexpr (C && !G::SPREAD) {
-      if (k + WS_AHEAD < n_my) {
-        WS_REQ(k + WS_AHEAD);
+      if (k + AHEAD < n_my) {
+        WS_REQ(k + AHEAD);
         requested = true;
       }
     }
@@ -381,7 +387,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
     });
   };
 
-  acc_t accA, accB;
+  acc_t accA;
+  if constexpr (!PIPE) {
+    for (int k = 0; k < n_my; ++k) {
+      step(accA, accA, yes_t{}, no_t{}, k);
+      step(accA, accA, no_t{}, yes_t{}, k + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  acc_t accB;
   step(accA, accB, yes_t{}, no_t{}, 0);
   for (int k = 1;;) {
     if (k >= n_my) { step(accB, accA, no_t{}, yes_t{}, k); break; }
@@ -396,23 +411,23 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ws_kernel(GemmWsParams p) {
 
 #undef WS_REQ
 
-template <int KS, int NT>
+template <int KS, int NT, bool PIPE = true>
 int launch_ws(GemmWsParams p, int N, int cus, hipStream_t stream) {
   typedef WsCfg<KS, NT> G;
-  const int nb = N / G::BN;
+  const int nb = N / G::BN, wgs = PIPE ? cus : 2 * cus;  // workgroups: one per CU, or two (the unpipelined 256-register form)
   if (nb < 1 || nb > 8 || N % G::BN) return -1;
-  if ((long)p.tiles_m * nb < 8L * cus) return -1;  // each workgroup loads 160-200 KB of W before its first 20-40 KB tile
+  if ((long)p.tiles_m * nb < 8L * wgs) return -1;  // each workgroup loads 160-200 KB of W before its first 20-40 KB tile
   p.nb = nb;
-  const int gx = (cus / 8) * 8;  // whole rounds of the 8 XCDs (see the kernel's slot mapping)
+  const int gx = (wgs / 8) * 8;  // whole rounds of the 8 XCDs (see the kernel's slot mapping)
   if (gx < 8 * nb) return -1;
-  constexpr int SMEM = WS_NS * G::STAGE;
+  constexpr int SMEM = (PIPE ? WS_NS : 2) * G::STAGE;
   static unsigned long long attr_done[2] = {0, 0};
   if (p.R) {
-    if (da_ensure_dyn_smem((const void*)gemm_nt_ws_kernel<KS, NT, true>, SMEM, &attr_done[1]) != DA_OK) return DA_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_nt_ws_kernel<KS, NT, true>), dim3(gx), dim3(256), SMEM, stream, p);
+    if (da_ensure_dyn_smem((const void*)gemm_nt_ws_kernel<KS, NT, true, 0, PIPE>, SMEM, &attr_done[1]) != DA_OK) return DA_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_nt_ws_kernel<KS, NT, true, 0, PIPE>), dim3(gx), dim3(256), SMEM, stream, p);
   } else {
-    if (da_ensure_dyn_smem((const void*)gemm_nt_ws_kernel<KS, NT, false>, SMEM, &attr_done[0]) != DA_OK) return DA_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_nt_ws_kernel<KS, NT, false>), dim3(gx), dim3(256), SMEM, stream, p);
+    if (da_ensure_dyn_smem((const void*)gemm_nt_ws_kernel<KS, NT, false, 0, PIPE>, SMEM, &attr_done[0]) != DA_OK) return DA_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_nt_ws_kernel<KS, NT, false, 0, PIPE>), dim3(gx), dim3(256), SMEM, stream, p);
   }
   DA_CHECK_LAUNCH();
   return DA_OK;
@@ -434,7 +449,7 @@ int da_gemm_nt_ws_try(const void* A, long lda, const void* W, const float* bias,
   p.lda = lda; p.ldr = ldr; p.ldc = ldc; p.M = M; p.N = N; p.tiles_m = M / WS_BM; p.nb = 1;
   p.G = nullptr; p.ldg = 0; p.inner = 0;
   if (K == 320) return N <= 1280 ? launch_ws<10, 5>(p, N, cus, stream) : -1;
-  return launch_ws<20, 2>(p, N, cus, stream);
+  return (g_nt_ws & 8) ? launch_ws<20, 2, false>(p, N, cus, stream) : launch_ws<20, 2>(p, N, cus, stream);  // bit 3: two workgroups per CU
 }
 
 // Called by da_gemm_nt_geglu (gemm_nt_v2.hip); -1 = not eligible.  K = 320 only: 128 hidden units per workgroup (each wave

@@ -74,7 +74,8 @@ int da_gemm_nt_geglu_bwd(const void* dY, long lddy, const void* Wt, const void* 
  *                       epilogue everywhere | 2 / 3 also the linears without / with a residual (measured slower).  Bit-identical.
  *   "gemm_nt_ws"        bit mask, default 1: bit 0 the K = 320 linears (N = 320 ... 1280, M % 32 == 0, >= 8 row tiles per CU) run in
  *                       the weight-stationary kernel (W in the registers of four waves; gemm_nt_ws.hip) | bit 1 the K = 640 linears
- *                       too | bit 2 the fused GEGLU forward at K = 320 too (both measured +-0 in the step).  Bit-identical.
+ *                       too | bit 2 the fused GEGLU forward at K = 320 too | bit 3 the K = 640 form as two unpipelined workgroups per
+ *                       CU (all three measured +-0 in the step).  Bit-identical.
  *   "gemm_nt_stream"    0 (default) | 1 / 2 the streaming short-K linear kernel (gemm_nt_v3.hip; slower) where it measured best /
  *                       wherever eligible; "gemm_nt_stream_lw" 4 | 16 its loader waves.  Bit-identical.
  *   "gemm_tn_ring"      0 (default) | 4 | 5: linear-layer weight gradients with a ring of 32-pixel half-stages (+-3 %).  Bit-identical.

@@ -519,12 +519,15 @@ def test_wgrad_v2_split_workspace(ops, dev):
 
 @pytest.mark.parametrize('M,N,K', [(65536, 320, 320), (32768 + 32, 320, 320), (32768 + 96, 960, 320), (65536 + 64, 640, 320),
                                    (32768 + 40, 320, 320), (65536, 640, 640), (16384 + 32, 640, 640), (16384 + 64, 1024, 640)])
-def test_gemm_nt_weight_stationary_form_equals_tiled_form(ops, dev, M, N, K):
+@pytest.mark.parametrize('opt', [3, 11])
+def test_gemm_nt_weight_stationary_form_equals_tiled_form(ops, dev, M, N, K, opt):
     """gemm_nt_ws.hip (K = 320 / 640 linears: the weight held in registers by four waves, activations streamed through an LDS
     ring, two-buffer software pipeline, direct epilogue; da_set_option('gemm_nt_ws', 3)) against the tiled form (0): same products, same order, same
     roundings -> BIT-identical, with / without bias and residual, an in-place residual, strided views, one and several
     320-column blocks, workgroups with 4 and 5 tiles (the pipeline's drain step on either accumulator set); M % 32 != 0 is
-    not a shape for it (the tiled form takes the call)."""
+    not a shape for it (the tiled form takes the call).  opt 11: the K = 640 form as two unpipelined workgroups per CU."""
+    if opt == 11 and K != 640:
+        pytest.skip('bit 3 only changes the K = 640 form')
     A = rnd(M, K, dev=dev, seed=1).to(BF); W = rnd(N, K, dev=dev, seed=2, scale=K**-0.5).to(BF)
     bias = rnd(N, dev=dev, seed=3); R = rnd(M, N, dev=dev, seed=4).to(BF)
     wide = rnd(M, N + 64, dev=dev, seed=5).to(BF); Awide = rnd(M, K + 64, dev=dev, seed=6).to(BF)
@@ -546,7 +549,7 @@ def test_gemm_nt_weight_stationary_form_equals_tiled_form(ops, dev, M, N, K):
     try:
         ops.set_option('gemm_nt_ws', 0)
         ref = run()
-        ops.set_option('gemm_nt_ws', 3)
+        ops.set_option('gemm_nt_ws', opt)
         got = run()
     finally:
         ops.set_option('gemm_nt_ws', 1)

@@ -1,10 +1,11 @@
 """A/B of da_set_option('gemm_nt_ws', 0 | 1) on the K = 320 / 640 linears of the batch-256 step (one process, interleaved rounds).
-usage: nt_ws_ab.py"""
+usage: nt_ws_ab.py [option value of the B arm = 3]"""
 import sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffusion_amd import ops
 dev = torch.device('cuda'); BF = torch.bfloat16
+OPT = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 CASES = [(262144, 320, 320), (262144, 960, 320), (65536, 640, 640), (262144, 640, 640)]
 
 
@@ -26,7 +27,7 @@ for M, N, K in CASES:
         ts = {0: [], 1: []}
         for rnd in range(7):
             for v in (0, 1):
-                ops.set_option('gemm_nt_ws', 3 * v)
+                ops.set_option('gemm_nt_ws', OPT * v)
                 fn(); ts[v].append(once(fn, 20))
         a, b = statistics.median(ts[0]), statistics.median(ts[1])
         fl = 2.0 * M * N * K
