@@ -16,8 +16,9 @@ def short(name):
     if m:
         args = [a.strip() for a in m.group(2).split(',')]
         return '%s<%s>' % (m.group(1).replace('_kernel', ''), ','.join(args[:4] if 'nt2' in m.group(1) else args[:2]))
-    m = re.search(r'(\w+_kernel\w*|\w+)', name.split('(')[0].split('::')[-1])
-    return m.group(1) if m else name[:40]
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    m = re.search(r'(\w+_kernel\w*(?:<[^>(]*>)?|\w+)', name.split('(')[0].split('::')[-1])
+    return m.group(1).replace(' ', '') if m else name[:40]
 
 
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
