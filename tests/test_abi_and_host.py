@@ -47,11 +47,12 @@ def test_set_option_keys_and_ranges(tmp_path):
     from diffusion_amd import _lib
     lib = _lib.load()
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'diffusion_amd.h')).read()
-    doc = hdr[hdr.index('int da_set_option') - 6000:hdr.index('int da_set_option')]
+    doc = hdr[hdr.index('/* tuning / test hooks'):hdr.index('int da_set_option')]
     keys = re.findall(r'^ \*   "([a-z0-9_]+)"', doc, flags=re.M)
-    assert {'gn_resident', 'gn_resident_form', 'reserve_cus', 'grad_overwrite', 'gemm_nt_persist_conv'} <= set(keys)
+    assert {'gn_resident', 'gn_resident_form', 'reserve_cus', 'grad_overwrite', 'gemm_nt_persist_conv', 'gemm_nt_ws', 'gemm_nt_de',
+            'attn_fused_bwd', 'gemm_tn_ring', 'gemm_nt_stream'} <= set(keys)
     defaults = {'gn_resident': 192, 'gn_resident_min_slab': 65536, 'gemm_nt_persist': -1, 'gemm_nt_dispatch': 1, 'gemm_nt_korder': 1, 'gemm_nt_splitk': 1,
-                'gemm_nt_persist_conv': 1}
+                'gemm_nt_persist_conv': 1, 'gemm_nt_de': 1, 'gemm_nt_ws': 1, 'attn_fused_bwd': 1}
     for k in keys:
         assert lib.da_set_option(k.encode(), defaults.get(k, 0)) == 0, k
     assert lib.da_set_option(b'no_such_option', 1) != 0
